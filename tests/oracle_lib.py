@@ -1,0 +1,222 @@
+"""ctypes bindings for the test-only CPU checkers.
+
+``oracle()``    -> oracle/liboracle.so, the plain-C restatement (always available,
+                   built by ``make -C oracle`` / ``__graft_entry__.build()``).
+``reference()`` -> oracle/_ref/libcpprcoder_ref.so, the unmodified reference header
+                   compiled in the build container (``make -C oracle ref``); None if absent.
+
+Both export the same entry points under the prefixes ``rco_`` / ``ref_`` so one
+``Checker`` class serves both.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libcpprcoder_ref.so")
+
+SUCCESS, PENDING, ERROR = 0, 1, -1
+
+
+class _Result(C.Structure):
+    _fields_ = [("status", C.c_int32), ("request_size", C.c_uint32)]
+
+
+def _u8(a) -> np.ndarray:
+    if isinstance(a, (bytes, bytearray, memoryview)):
+        return np.frombuffer(bytes(a), dtype=np.uint8)
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+class Checker:
+    def __init__(self, path: str, prefix: str, kind: str):
+        self.lib = C.CDLL(path)
+        self.prefix = prefix
+        self.kind = kind  # "port" (restatement) or "reference"
+        p, L = prefix, self.lib
+        u8p, u64p, u32p, i32p = C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p
+        self._aenc = getattr(L, p + "adaptive_encode")
+        self._aenc.restype, self._aenc.argtypes = _Result, [u8p, C.c_uint32, u8p, C.c_uint64, u64p]
+        self._adec = getattr(L, p + "adaptive_decode")
+        self._adec.restype, self._adec.argtypes = _Result, [u8p, C.c_uint64, u8p, C.c_uint64, u64p]
+        self._aencc = getattr(L, p + "adaptive_encode_chunked")
+        self._aencc.restype, self._aencc.argtypes = _Result, [u8p, C.c_uint32, C.c_uint32, u8p, C.c_uint64, u64p]
+        self._adecc = getattr(L, p + "adaptive_decode_chunked")
+        self._adecc.restype, self._adecc.argtypes = _Result, [u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint64, u64p]
+        self._senc = getattr(L, p + "static_encode")
+        self._senc.restype, self._senc.argtypes = C.c_int, [u8p, C.c_uint32, u8p, C.c_uint64, u64p]
+        self._sdec = getattr(L, p + "static_decode")
+        self._sdec.restype, self._sdec.argtypes = C.c_int, [u8p, C.c_uint32, u8p, C.c_uint64, u64p]
+        self._ebr = getattr(L, p + "encode_block_range")
+        self._ebr.restype = C.c_int
+        self._ebr.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, u8p, C.c_uint64, u32p, C.c_int]
+        self._dbr = getattr(L, p + "decode_block_range")
+        self._dbr.restype = C.c_int
+        self._dbr.argtypes = [u8p, C.c_uint64, u32p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, u8p, C.c_int]
+        self._probe = getattr(L, p + "model_probe")
+        self._probe.restype = None
+        self._probe.argtypes = [u8p, C.c_uint64, u32p, u32p, u32p, u32p, C.c_uint32, u32p, u8p]
+        self._script = getattr(L, p + "stream_script")
+        self._script.restype, self._script.argtypes = C.c_int, [i32p, C.c_int, i32p]
+
+    # ---- one-shot streams -------------------------------------------------
+    @staticmethod
+    def default_capacity(n: int) -> int:
+        return n + n // 32 + 1024
+
+    def _oneshot(self, fn, data, sink_capacity, *mid):
+        src = _u8(data)
+        cap = self.default_capacity(len(src)) if sink_capacity is None else int(sink_capacity)
+        out = np.zeros(max(cap, 16) + 32, dtype=np.uint8)
+        size = C.c_uint64()
+        res = fn(src.ctypes.data, len(src), *mid, out.ctypes.data, cap, C.byref(size))
+        return res, bytes(out[: min(size.value, cap)]), size.value
+
+    def adaptive_encode(self, data, sink_capacity=None):
+        """-> ((status, request_size), stream bytes, stream size)"""
+        res, out, size = self._oneshot(self._aenc, data, sink_capacity)
+        return (res.status, res.request_size), out, size
+
+    def adaptive_encode_chunked(self, data, piece, sink_capacity=None):
+        res, out, size = self._oneshot(self._aencc, data, sink_capacity, piece)
+        return (res.status, res.request_size), out, size
+
+    def adaptive_decode(self, comp, sink_capacity):
+        res, out, size = self._oneshot(self._adec, comp, sink_capacity)
+        return (res.status, res.request_size), out, size
+
+    def adaptive_decode_chunked(self, comp, piece, sink_capacity):
+        res, out, size = self._oneshot(self._adecc, comp, sink_capacity, piece)
+        return (res.status, res.request_size), out, size
+
+    def static_encode(self, data, sink_capacity=None):
+        src = _u8(data)
+        cap = (len(src) + len(src) // 32 + 2048) if sink_capacity is None else int(sink_capacity)
+        ok, out, size = self._oneshot(self._senc, src, cap)
+        return bool(ok), out, size
+
+    def static_decode(self, comp, sink_capacity):
+        ok, out, size = self._oneshot(self._sdec, comp, sink_capacity)
+        return bool(ok), out, size
+
+    # ---- many blocks ------------------------------------------------------
+    @staticmethod
+    def block_bound(block: int) -> int:
+        b = block + block // 32 + 1024
+        return (b + 15) & ~15
+
+    def encode_blocks(self, data, block: int, coder: int = 0, threads: int = 1):
+        """-> (slots[nblocks, slot] u8, sizes[nblocks] u32).  Threads split the block range
+        (ctypes drops the GIL for the duration of each call)."""
+        src = _u8(data)
+        n = len(src)
+        nblocks = (n + block - 1) // block
+        slot = self.block_bound(block)
+        slots = np.zeros((nblocks, slot), dtype=np.uint8)
+        sizes = np.zeros(nblocks, dtype=np.uint32)
+        oks = []
+
+        def work(first, last):
+            oks.append(self._ebr(src.ctypes.data, n, block, first, last, slots.ctypes.data, slot, sizes.ctypes.data, coder))
+
+        self._fan_out(work, nblocks, threads)
+        if not all(oks):
+            raise RuntimeError(f"{self.prefix}encode_block_range reported a failure")
+        return slots, sizes
+
+    def decode_blocks(self, slots, sizes, block: int, n: int, coder: int = 0, threads: int = 1):
+        slots = np.ascontiguousarray(slots, dtype=np.uint8)
+        sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+        nblocks, slot = slots.shape
+        out = np.zeros(n, dtype=np.uint8)
+        oks = []
+
+        def work(first, last):
+            oks.append(self._dbr(slots.ctypes.data, slot, sizes.ctypes.data, block, n, first, last, out.ctypes.data, coder))
+
+        self._fan_out(work, nblocks, threads)
+        return out, all(oks)
+
+    @staticmethod
+    def _fan_out(work, nblocks, threads):
+        threads = max(1, min(threads, nblocks))
+        if threads == 1:
+            work(0, nblocks)
+            return
+        cuts = [nblocks * i // threads for i in range(threads + 1)]
+        pool = [threading.Thread(target=work, args=(cuts[i], cuts[i + 1])) for i in range(threads)]
+        for t in pool:
+            t.start()
+        for t in pool:
+            t.join()
+
+    @staticmethod
+    def compact(slots, sizes):
+        """Concatenate the per-block streams -> (payload bytes, offsets[nblocks+1] u64)."""
+        sizes = np.asarray(sizes, dtype=np.uint64)
+        offsets = np.zeros(len(sizes) + 1, dtype=np.uint64)
+        np.cumsum(sizes, out=offsets[1:])
+        payload = np.concatenate([slots[b, : int(sizes[b])] for b in range(len(sizes))]) if len(sizes) else np.zeros(0, np.uint8)
+        return payload, offsets
+
+    # ---- probes -----------------------------------------------------------
+    def model_probe(self, symbols, targets):
+        syms = _u8(symbols)
+        tg = np.ascontiguousarray(targets, dtype=np.uint32)
+        total = np.zeros(1, dtype=np.uint32)
+        freq = np.zeros(256, dtype=np.uint32)
+        cum = np.zeros(256, dtype=np.uint32)
+        fcount = np.zeros(len(tg), dtype=np.uint32)
+        fcode = np.zeros(len(tg), dtype=np.uint8)
+        self._probe(syms.ctypes.data, len(syms), total.ctypes.data, freq.ctypes.data, cum.ctypes.data,
+                    tg.ctypes.data, len(tg), fcount.ctypes.data, fcode.ctypes.data)
+        return int(total[0]), freq, cum, fcount, fcode
+
+    def stream_script(self, ops):
+        """ops: [(opcode, arg), ...] -> [(ret, capacity, size), ...] (see ref_shim.cpp)."""
+        flat = np.asarray(ops, dtype=np.int32).reshape(-1)
+        out = np.zeros(3 * len(ops), dtype=np.int32)
+        w = self._script(flat.ctypes.data, len(ops), out.ctypes.data)
+        assert w == 3 * len(ops)
+        return [tuple(int(v) for v in out[3 * i: 3 * i + 3]) for i in range(len(ops))]
+
+
+def build_oracle(force: bool = False) -> None:
+    """Compile the C restatement (and the reference build when /root/reference exists)."""
+    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(ORACLE_DIR, "rc_oracle.c")):
+        subprocess.run(["make", "-C", ORACLE_DIR, "all"], check=True, capture_output=True)
+    ref_header = os.environ.get("RCX_REFERENCE", "/root/reference")
+    if os.path.exists(os.path.join(ref_header, "cpprcoder.h")):
+        subprocess.run(["make", "-C", ORACLE_DIR, "ref", f"REFERENCE={ref_header}"], check=True, capture_output=True)
+
+
+_cache: dict[str, Checker | None] = {}
+
+
+def oracle() -> Checker:
+    if "o" not in _cache:
+        if not os.path.exists(ORACLE_SO):
+            build_oracle()
+        _cache["o"] = Checker(ORACLE_SO, "rco_", "port")
+    return _cache["o"]
+
+
+def reference() -> Checker | None:
+    if "r" not in _cache:
+        _cache["r"] = Checker(REF_SO, "ref_", "reference") if os.path.exists(REF_SO) else None
+    return _cache["r"]
+
+
+def fnv1a64(data) -> int:
+    lib = oracle().lib
+    lib.rco_fnv1a64.restype, lib.rco_fnv1a64.argtypes = C.c_uint64, [C.c_void_p, C.c_uint64]
+    a = _u8(data)
+    return int(lib.rco_fnv1a64(a.ctypes.data, len(a)))
