@@ -1,0 +1,48 @@
+"""Build the native library in-tree: hipcc --offload-arch=gfx950 -> cpprcoder_amd/librcx.so.
+
+hipcc cross-compiles gfx950 without a GPU, so this also runs in the CPU-only build container.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "librcx.so")
+SOURCES = ["rcx_api.hip"]
+HEADERS = ["rcx_lane.hpp", "rcx_divtab.hpp", "rcx_kernels.hpp", os.path.join("..", "..", "include", "rcx.h")]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP library cannot be built")
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not stale():
+        return LIB
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or proc.returncode != 0:
+        print(" ".join(cmd))
+        print(proc.stdout, proc.stderr)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + proc.stderr[-4000:])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

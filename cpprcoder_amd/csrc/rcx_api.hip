@@ -1,0 +1,493 @@
+// rcx_api.hip -- the C ABI of include/rcx.h on top of the gfx950 kernels.
+//
+// Host-side restatement of the reference's driver code path: where
+// test/main.cpp:321-344 constructs a MemoryStream and a coder per buffer and
+// calls initialize/encode/decode, a caller here makes one rcx_ctx per GPU and
+// calls rcx_encode_blocks_device / rcx_decode_blocks_device per buffer.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/rcx.h"
+#include "rcx_divtab.hpp"
+#include "rcx_kernels.hpp"
+
+namespace
+{
+
+#define HIP_TRY(expr)                         \
+    do {                                      \
+        hipError_t e_ = (expr);               \
+        if (e_ != hipSuccess) return RCX_E_HIP; \
+    } while (0)
+
+struct EventPair {
+    hipEvent_t a, b;
+    int what;
+};
+
+} // namespace
+
+struct rcx_ctx {
+    int device = 0;
+    // scratch
+    u8* slots = nullptr;
+    u64 slots_bytes = 0;
+    u32* sizes = nullptr;
+    u64 sizes_count = 0;
+    DivEntry* divtab = nullptr;
+    u32 divtab_block = 0;
+    u32* status = nullptr;      // device: [flags, first bad block, track0, track1]
+    u32* status_host = nullptr; // pinned, same 4 words
+    // staging for the host-pointer entry points
+    u8* h_in = nullptr;
+    u64 h_in_bytes = 0;
+    u8* h_out = nullptr;
+    u64 h_out_bytes = 0;
+    u64* h_off = nullptr;
+    u64 h_off_count = 0;
+    // timing
+    bool timing = false;
+    std::vector<EventPair> pending;
+    std::vector<EventPair> pool;
+    double ms[RCX_T_COUNT] = {0, 0, 0, 0};
+    uint64_t launches[RCX_T_COUNT] = {0, 0, 0, 0};
+};
+
+namespace
+{
+
+struct Timed {
+    rcx_ctx* c;
+    hipStream_t s;
+    EventPair p;
+    bool on;
+    Timed(rcx_ctx* ctx, hipStream_t st, int what) : c(ctx), s(st), on(ctx->timing)
+    {
+        if (!on) return;
+        if (!c->pool.empty()) {
+            p = c->pool.back();
+            c->pool.pop_back();
+        } else if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) {
+            on = false;
+            return;
+        }
+        p.what = what;
+        hipEventRecord(p.a, s);
+    }
+    ~Timed()
+    {
+        if (!on) return;
+        hipEventRecord(p.b, s);
+        c->pending.push_back(p);
+    }
+};
+
+int grow(void** p, u64* have, u64 want)
+{
+    if (*have >= want) return RCX_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *have = 0;
+    if (hipMalloc(p, want) != hipSuccess) return RCX_E_NOMEM;
+    *have = want;
+    return RCX_OK;
+}
+
+int ensure_divtab(rcx_ctx* c, u32 block)
+{
+    if (c->divtab && c->divtab_block >= block) return RCX_OK;
+    // round up so that a sweep of block sizes builds the table once or twice
+    u32 cover = 1u << 16;
+    while (cover < block) cover <<= 1;
+    const u64 entries = (u64)cover + 2 * RCX_STAGE;
+    std::vector<DivEntry> host(entries);
+    for (u64 i = 0; i < entries; ++i) host[i] = rcx_make_div_entry((u32)(256 + i));
+    if (c->divtab) (void)hipFree(c->divtab);
+    c->divtab = nullptr;
+    c->divtab_block = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&c->divtab), entries * sizeof(DivEntry)) != hipSuccess) return RCX_E_NOMEM;
+    if (hipMemcpy(c->divtab, host.data(), entries * sizeof(DivEntry), hipMemcpyHostToDevice) != hipSuccess) return RCX_E_HIP;
+    c->divtab_block = cover;
+    return RCX_OK;
+}
+
+bool block_ok(uint32_t block) { return block >= RCX_MIN_BLOCK && block <= RCX_MAX_BLOCK; }
+
+int reserve(rcx_ctx* c, u64 n, u32 block)
+{
+    const u64 nblocks = rcx_block_count(n, block);
+    const u64 slot = rcx_block_bound(block);
+    int r = ensure_divtab(c, block);
+    if (r != RCX_OK) return r;
+    r = grow(reinterpret_cast<void**>(&c->slots), &c->slots_bytes, nblocks * slot + 256);
+    if (r != RCX_OK) return r;
+    u64 bytes = c->sizes_count * sizeof(u32);
+    r = grow(reinterpret_cast<void**>(&c->sizes), &bytes, (nblocks + 1) * sizeof(u32));
+    if (r != RCX_OK) return r;
+    c->sizes_count = bytes / sizeof(u32);
+    return RCX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int rcx_version(void) { return RCX_VERSION; }
+
+const char* rcx_status_string(int status)
+{
+    switch (status) {
+    case RCX_OK: return "success";
+    case RCX_PENDING: return "pending";
+    case RCX_ERROR: return "error";
+    case RCX_E_ARG: return "bad argument";
+    case RCX_E_CAPACITY: return "destination too small";
+    case RCX_E_CORRUPT: return "corrupt or truncated block stream";
+    case RCX_E_HIP: return "HIP runtime error";
+    case RCX_E_NOMEM: return "out of memory";
+    default: return "unknown status";
+    }
+}
+
+uint64_t rcx_block_count(uint64_t n, uint32_t block) { return block ? (n + block - 1) / block : 0; }
+
+// Worst case of one adaptive block: n + (255/2)*log2(n)/8 (estimator regret) + the
+// truncation loss of t = range/total, < n/64 for block <= 2^20; plus the 9 framing bytes.
+// The static coder needs 521 + n + slack.  Rounded to 16 so slots keep 16-byte alignment.
+uint64_t rcx_block_bound(uint32_t block)
+{
+    uint64_t b = (uint64_t)block + block / 32 + 1024;
+    return (b + 15) & ~(uint64_t)15;
+}
+
+uint64_t rcx_encode_bound(uint64_t n, uint32_t block) { return rcx_block_count(n, block) * rcx_block_bound(block) + 16; }
+
+int rcx_ctx_create(int device, rcx_ctx** out)
+{
+    if (!out) return RCX_E_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return RCX_E_HIP; // no CPU fallback: fail loudly
+    if (device < 0 || device >= count) return RCX_E_ARG;
+    HIP_TRY(hipSetDevice(device));
+    rcx_ctx* c = new (std::nothrow) rcx_ctx();
+    if (!c) return RCX_E_NOMEM;
+    c->device = device;
+    if (hipMalloc(reinterpret_cast<void**>(&c->status), 4 * sizeof(u32)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&c->status_host), 4 * sizeof(u32), hipHostMallocDefault) != hipSuccess) {
+        rcx_ctx_destroy(c);
+        return RCX_E_NOMEM;
+    }
+    const u32 init[2] = {0u, 0xFFFFFFFFu};
+    if (hipMemcpy(c->status, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) {
+        rcx_ctx_destroy(c);
+        return RCX_E_HIP;
+    }
+    *out = c;
+    return RCX_OK;
+}
+
+void rcx_ctx_destroy(rcx_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto& p : c->pending) c->pool.push_back(p);
+    for (auto& p : c->pool) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    if (c->slots) (void)hipFree(c->slots);
+    if (c->sizes) (void)hipFree(c->sizes);
+    if (c->divtab) (void)hipFree(c->divtab);
+    if (c->status) (void)hipFree(c->status);
+    if (c->status_host) (void)hipHostFree(c->status_host);
+    if (c->h_in) (void)hipFree(c->h_in);
+    if (c->h_out) (void)hipFree(c->h_out);
+    if (c->h_off) (void)hipFree(c->h_off);
+    delete c;
+}
+
+int rcx_ctx_reserve(rcx_ctx* c, uint64_t n, uint32_t block)
+{
+    if (!c || !block_ok(block)) return RCX_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    return reserve(c, n, block);
+}
+
+int rcx_ctx_sync_status(rcx_ctx* c, void* stream, uint64_t* first_bad_block)
+{
+    if (!c) return RCX_E_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->status_host, c->status, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
+    const u32 init[2] = {0u, 0xFFFFFFFFu};
+    HIP_TRY(hipStreamSynchronize(s));
+    const u32 flags = c->status_host[0], bad = c->status_host[1];
+    if (flags) {
+        HIP_TRY(hipMemcpyAsync(c->status, init, sizeof(init), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    if (first_bad_block) *first_bad_block = bad;
+    if (flags & RCX_ST_CORRUPT) return RCX_E_CORRUPT;
+    if (flags & RCX_ST_CAPACITY) return RCX_E_CAPACITY;
+    return RCX_OK;
+}
+
+int rcx_encode_blocks_device(rcx_ctx* c, int coder, const void* d_src, uint64_t n, uint32_t block,
+                             void* d_dst, uint64_t dst_cap, uint64_t* d_offsets, void* stream)
+{
+    if (!c || !block_ok(block) || !d_offsets || (n && (!d_src || !d_dst))) return RCX_E_ARG;
+    if (coder != RCX_CODER_ADAPTIVE) return RCX_E_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(c->device));
+    const u64 nblocks = rcx_block_count(n, block);
+    if (nblocks == 0) return hipMemsetAsync(d_offsets, 0, sizeof(u64), s) == hipSuccess ? RCX_OK : RCX_E_HIP;
+    if (nblocks > 0x7FFFFFFFull) return RCX_E_ARG;
+    int r = reserve(c, n, block);
+    if (r != RCX_OK) return r;
+    const u64 slot = rcx_block_bound(block);
+    {
+        Timed t(c, s, RCX_T_ENCODE);
+        const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
+        hipLaunchKernelGGL(rcx_enc_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block, nblocks,
+                           c->slots, slot, c->sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr));
+    }
+    {
+        Timed t(c, s, RCX_T_SCAN);
+        hipLaunchKernelGGL(rcx_scan_sizes_k, dim3(1), dim3(1024), 0, s, c->sizes, nblocks, d_offsets, dst_cap, c->status);
+    }
+    {
+        Timed t(c, s, RCX_T_SCATTER);
+        hipLaunchKernelGGL(rcx_scatter_k, dim3((u32)nblocks), dim3(256), 0, s, c->slots, slot, c->sizes, d_offsets,
+                           static_cast<u8*>(d_dst), dst_cap);
+    }
+    return hipGetLastError() == hipSuccess ? RCX_OK : RCX_E_HIP;
+}
+
+int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t comp_size,
+                             const uint64_t* d_offsets, uint64_t nblocks, uint32_t block,
+                             uint64_t n, void* d_dst, void* stream)
+{
+    (void)comp_size;
+    if (!c || !block_ok(block) || (nblocks && (!d_comp || !d_offsets || !d_dst))) return RCX_E_ARG;
+    if (coder != RCX_CODER_ADAPTIVE) return RCX_E_ARG;
+    if (nblocks != rcx_block_count(n, block)) return RCX_E_ARG;
+    if (nblocks == 0) return RCX_OK;
+    if (nblocks > 0x7FFFFFFFull) return RCX_E_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(c->device));
+    int r = ensure_divtab(c, block);
+    if (r != RCX_OK) return r;
+    {
+        Timed t(c, s, RCX_T_DECODE);
+        const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
+        hipLaunchKernelGGL(rcx_dec_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
+                           block, n, static_cast<u8*>(d_dst), c->divtab, c->status, static_cast<u32*>(nullptr));
+    }
+    return hipGetLastError() == hipSuccess ? RCX_OK : RCX_E_HIP;
+}
+
+int rcx_encode_blocks(rcx_ctx* c, int coder, const uint8_t* src, uint64_t n, uint32_t block,
+                      uint8_t* dst, uint64_t dst_cap, uint64_t* dst_size, uint64_t* offsets)
+{
+    if (!c || !block_ok(block) || !dst_size || (n && (!src || !dst))) return RCX_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    *dst_size = 0;
+    const u64 nblocks = rcx_block_count(n, block);
+    const u64 bound = rcx_encode_bound(n, block);
+    int r = grow(reinterpret_cast<void**>(&c->h_in), &c->h_in_bytes, n + 64);
+    if (r != RCX_OK) return r;
+    r = grow(reinterpret_cast<void**>(&c->h_out), &c->h_out_bytes, bound + 64);
+    if (r != RCX_OK) return r;
+    u64 off_bytes = c->h_off_count * sizeof(u64);
+    r = grow(reinterpret_cast<void**>(&c->h_off), &off_bytes, (nblocks + 1) * sizeof(u64));
+    if (r != RCX_OK) return r;
+    c->h_off_count = off_bytes / sizeof(u64);
+    if (n) HIP_TRY(hipMemcpy(c->h_in, src, n, hipMemcpyHostToDevice));
+    r = rcx_encode_blocks_device(c, coder, c->h_in, n, block, c->h_out, bound, c->h_off, nullptr);
+    if (r != RCX_OK) return r;
+    r = rcx_ctx_sync_status(c, nullptr, nullptr);
+    if (r != RCX_OK) return r;
+    u64 total = 0;
+    HIP_TRY(hipMemcpy(&total, c->h_off + nblocks, sizeof(u64), hipMemcpyDeviceToHost));
+    *dst_size = total;
+    if (offsets) HIP_TRY(hipMemcpy(offsets, c->h_off, (nblocks + 1) * sizeof(u64), hipMemcpyDeviceToHost));
+    if (total > dst_cap) return RCX_E_CAPACITY;
+    if (total) HIP_TRY(hipMemcpy(dst, c->h_out, total, hipMemcpyDeviceToHost));
+    return RCX_OK;
+}
+
+int rcx_decode_blocks(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_size,
+                      const uint64_t* offsets, uint64_t nblocks, uint32_t block,
+                      uint8_t* dst, uint64_t dst_cap, uint64_t* dst_size)
+{
+    if (!c || !block_ok(block) || !dst_size || (nblocks && (!comp || !offsets || !dst))) return RCX_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    *dst_size = 0;
+    if (nblocks == 0) return RCX_OK;
+    if (offsets[nblocks] > comp_size || offsets[nblocks] < offsets[nblocks - 1] || offsets[nblocks] - offsets[nblocks - 1] < 4)
+        return RCX_E_CORRUPT;
+    // the last block's declared size fixes n (every earlier block is full)
+    const uint8_t* lastp = comp + offsets[nblocks - 1];
+    const u64 last_len = (u64)lastp[0] | ((u64)lastp[1] << 8) | ((u64)lastp[2] << 16) | ((u64)lastp[3] << 24);
+    if (last_len == 0 || last_len > block) return RCX_E_CORRUPT;
+    const u64 n = (nblocks - 1) * (u64)block + last_len;
+    if (n > dst_cap) return RCX_E_CAPACITY;
+    int r = grow(reinterpret_cast<void**>(&c->h_in), &c->h_in_bytes, comp_size + 64);
+    if (r != RCX_OK) return r;
+    r = grow(reinterpret_cast<void**>(&c->h_out), &c->h_out_bytes, n + 64);
+    if (r != RCX_OK) return r;
+    u64 off_bytes = c->h_off_count * sizeof(u64);
+    r = grow(reinterpret_cast<void**>(&c->h_off), &off_bytes, (nblocks + 1) * sizeof(u64));
+    if (r != RCX_OK) return r;
+    c->h_off_count = off_bytes / sizeof(u64);
+    HIP_TRY(hipMemcpy(c->h_in, comp, comp_size, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->h_off, offsets, (nblocks + 1) * sizeof(u64), hipMemcpyHostToDevice));
+    r = rcx_decode_blocks_device(c, coder, c->h_in, comp_size, c->h_off, nblocks, block, n, c->h_out, nullptr);
+    if (r != RCX_OK) return r;
+    r = rcx_ctx_sync_status(c, nullptr, nullptr);
+    if (r != RCX_OK) return r;
+    HIP_TRY(hipMemcpy(dst, c->h_out, n, hipMemcpyDeviceToHost));
+    *dst_size = n;
+    return RCX_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// Single streams with the reference's sink semantics (one block, lane 0 of one wave).
+// ---------------------------------------------------------------------------
+namespace
+{
+u64 sink_round16(u64 cap) { return cap == 0 ? 16 : (cap + 15) & ~(u64)15; } // cpprcoder.h:975
+}
+
+int rcx_stream_encode(rcx_ctx* c, int coder, const uint8_t* src, uint32_t n,
+                      uint8_t* dst, uint64_t sink_capacity, uint64_t* dst_size, uint32_t* request_size)
+{
+    if (!c || !dst || !dst_size || (n && !src)) return RCX_E_ARG;
+    if (coder != RCX_CODER_ADAPTIVE || n > RCX_MAX_BLOCK) return RCX_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    *dst_size = 0;
+    if (request_size) *request_size = 0;
+    const u32 block = n < RCX_MIN_BLOCK ? RCX_MIN_BLOCK : n;
+    int r = reserve(c, block, block);
+    if (r != RCX_OK) return r;
+    r = grow(reinterpret_cast<void**>(&c->h_in), &c->h_in_bytes, (u64)n + 64);
+    if (r != RCX_OK) return r;
+    if (n) HIP_TRY(hipMemcpy(c->h_in, src, n, hipMemcpyHostToDevice));
+    const u64 slot = rcx_block_bound(block);
+    hipLaunchKernelGGL(rcx_enc_adaptive_k<false>, dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)n, block, (u64)1, c->slots, slot,
+                       c->sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr));
+    if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
+    r = rcx_ctx_sync_status(c, nullptr, nullptr);
+    if (r != RCX_OK) return r;
+    u32 size = 0;
+    HIP_TRY(hipMemcpy(&size, c->sizes, sizeof(u32), hipMemcpyDeviceToHost));
+    const u64 cap16 = sink_round16(sink_capacity);
+    if ((u64)size - 4 <= cap16) { // every writeByte fits; the final write(4) grows the sink (cpprcoder.h:1031-1045)
+        HIP_TRY(hipMemcpy(dst, c->slots, size, hipMemcpyDeviceToHost));
+        *dst_size = size;
+        return RCX_OK;
+    }
+    // The sink fills.  Second pass: replay the reference's delayed writer to find the symbol.
+    hipLaunchKernelGGL(rcx_enc_adaptive_k<true>, dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)n, block, (u64)1, c->slots, slot,
+                       c->sizes, c->divtab, c->status, (u32)(cap16 - 4), c->status + 2);
+    if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
+    HIP_TRY(hipMemcpy(c->status_host, c->status, 4 * sizeof(u32), hipMemcpyDeviceToHost));
+    const u32 fail_at = c->status_host[2];
+    HIP_TRY(hipMemcpy(dst, c->slots, cap16, hipMemcpyDeviceToHost)); // what was written before the sink filled
+    *dst_size = cap16;
+    if (fail_at != 0xFFFFFFFFu) { // cpprcoder.h:708-711
+        if (request_size) *request_size = n - fail_at;
+        return RCX_PENDING;
+    }
+    return RCX_OK; // only finish() failed and encode() ignores that (cpprcoder.h:716)
+}
+
+int rcx_stream_decode(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_size,
+                      uint8_t* dst, uint64_t sink_capacity, uint64_t* dst_size, uint32_t* request_size)
+{
+    if (!c || !dst || !dst_size || (comp_size && !comp)) return RCX_E_ARG;
+    if (coder != RCX_CODER_ADAPTIVE || comp_size > 0x7FFFFFFFull) return RCX_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    *dst_size = 0;
+    if (request_size) *request_size = 0;
+    if (comp_size < 8) { // cpprcoder.h:878-880
+        if (request_size) *request_size = 8;
+        return RCX_PENDING;
+    }
+    const u32 declared = (u32)comp[0] | ((u32)comp[1] << 8) | ((u32)comp[2] << 16) | ((u32)comp[3] << 24);
+    const u64 cap16 = sink_round16(sink_capacity);
+    const u64 want = declared ? declared : 1; // cpprcoder.h:912: the size test comes after the first writeByte
+    const u64 count = want < cap16 ? want : cap16;
+    if (count > RCX_MAX_BLOCK) return RCX_E_ARG;
+    const u32 block = count < RCX_MIN_BLOCK ? RCX_MIN_BLOCK : (u32)count;
+    int r = ensure_divtab(c, block);
+    if (r != RCX_OK) return r;
+    r = grow(reinterpret_cast<void**>(&c->h_in), &c->h_in_bytes, comp_size + 64);
+    if (r != RCX_OK) return r;
+    r = grow(reinterpret_cast<void**>(&c->h_out), &c->h_out_bytes, count + 64);
+    if (r != RCX_OK) return r;
+    u64 off_bytes = c->h_off_count * sizeof(u64);
+    r = grow(reinterpret_cast<void**>(&c->h_off), &off_bytes, 2 * sizeof(u64));
+    if (r != RCX_OK) return r;
+    c->h_off_count = off_bytes / sizeof(u64);
+    const u64 offs[2] = {0, comp_size};
+    HIP_TRY(hipMemcpy(c->h_in, comp, comp_size, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->h_off, offs, sizeof(offs), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rcx_dec_adaptive_k<true>, dim3(1), dim3(64), 0, nullptr, c->h_in, c->h_off, (u64)1, block, count, c->h_out,
+                       c->divtab, c->status, c->status + 2);
+    if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
+    HIP_TRY(hipMemcpy(c->status_host, c->status, 4 * sizeof(u32), hipMemcpyDeviceToHost));
+    const u32 short_at = c->status_host[2];
+    u64 produced = count;
+    int result = RCX_OK;
+    if (short_at != 0xFFFFFFFFu && short_at < count) { // input ran dry first (cpprcoder.h:901-903)
+        produced = short_at;
+        result = RCX_PENDING;
+    } else if (want > cap16) { // sink full (cpprcoder.h:909-911)
+        result = RCX_PENDING;
+    }
+    if (result == RCX_PENDING && request_size) *request_size = declared - (u32)produced;
+    if (produced) HIP_TRY(hipMemcpy(dst, c->h_out, produced, hipMemcpyDeviceToHost));
+    *dst_size = produced;
+    return result;
+}
+
+int rcx_ctx_set_timing(rcx_ctx* c, int enabled)
+{
+    if (!c) return RCX_E_ARG;
+    c->timing = enabled != 0;
+    return RCX_OK;
+}
+
+int rcx_ctx_get_timing(rcx_ctx* c, double* ms, uint64_t* launches, int reset)
+{
+    if (!c) return RCX_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    for (auto& p : c->pending) {
+        float t = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) {
+            c->ms[p.what] += t;
+            c->launches[p.what] += 1;
+        }
+        c->pool.push_back(p);
+    }
+    c->pending.clear();
+    for (int i = 0; i < RCX_T_COUNT; ++i) {
+        if (ms) ms[i] = c->ms[i];
+        if (launches) launches[i] = c->launches[i];
+        if (reset) {
+            c->ms[i] = 0;
+            c->launches[i] = 0;
+        }
+    }
+    return RCX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,286 @@
+// rcx_kernels.hpp -- gfx950 kernels of the many-block adaptive range coder.
+//
+//   rcx_enc_adaptive_k   pass 1: one lane per block, 64 blocks per wave, one wave per
+//                        workgroup; every block's stream goes to its scratch slot and
+//                        its size to sizes[].      (cpprcoder.h:678-802, 1094-1187)
+//   rcx_scan_sizes_k     size prefix: exclusive scan of sizes[] -> offsets[] (u64)
+//   rcx_scatter_k        pass 2: compacted scatter of the slots to dst + offsets[b]
+//                        (the reference's MemoryStream is the sink, cpprcoder.h:1031-1054)
+//   rcx_dec_adaptive_k   one lane per block decode.  (cpprcoder.h:859-940, 1189-1243)
+//
+// Roofline class: HBM-bound integer/byte work, no MFMA.  What actually bounds the two
+// coder kernels is the serial dependency chain of one symbol (divide -> multiply ->
+// renormalise -> table update) times the number of blocks in flight; see DESIGN.md.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rcx_lane.hpp"
+
+#define RCX_ST_CAPACITY 1u
+#define RCX_ST_CORRUPT 2u
+
+// status[0] = OR of RCX_ST_* flags, status[1] = lowest failing block (saturated to u32)
+__device__ __forceinline__ void rcx_flag(u32* status, u32 what, u64 blk)
+{
+    atomicOr(&status[0], what);
+    atomicMin(&status[1], blk > 0xFFFFFFFEull ? 0xFFFFFFFEu : (u32)blk);
+}
+
+__device__ __forceinline__ u32 rcx_wave_max(u32 v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        u32 other = (u32)__shfl_xor((int)v, o, 64);
+        v = v > other ? v : other;
+    }
+    return v;
+}
+
+__device__ __forceinline__ u32 rcx_byte_of(const U4& w, u32 j)
+{
+    const u32 word = (j < 4) ? w.x : (j < 8) ? w.y : (j < 12) ? w.z : w.w;
+    return (word >> (8 * (j & 3))) & 0xFFu;
+}
+
+// LDS image of one wave: the 64 lane-interleaved trees, then 64 staged divisor entries.
+#define RCX_LDS_U4 ((RCX_GROUPS + 1) * RCX_LANES)
+
+// ===========================================================================
+// Encode, pass 1
+// ===========================================================================
+// STREAM = the single-stream entry point's second pass: one block, and the lane also
+// replays the reference's delayed writer to find where a bounded sink fills
+// (track[0] = failing symbol or 0xFFFFFFFF, track[1] = 1 if only the final flush fails).
+template <bool STREAM>
+__global__ __launch_bounds__(64) void rcx_enc_adaptive_k(const u8* __restrict__ src, u64 n, u32 block, u64 nblocks,
+                                                         u8* __restrict__ slots, u64 slot, u32* __restrict__ sizes,
+                                                         const DivEntry* __restrict__ divtab, u32* status,
+                                                         u32 sink_bytes, u32* track)
+{
+    __shared__ U4 lds[RCX_LDS_U4];
+    const u32 lane = threadIdx.x;
+    const u64 blk = (u64)blockIdx.x * RCX_LANES + lane;
+    const bool live = blk < nblocks;
+    const u64 at = live ? blk * (u64)block : 0;
+    const u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
+
+    Tree tree{lds + lane};
+    tree.reset();
+    DivEntry* stage = reinterpret_cast<DivEntry*>(lds + RCX_GROUPS * RCX_LANES);
+
+    EncLane enc;
+    if (live) enc.begin(slots + blk * slot, (u32)slot, len);
+    else enc.idle();
+    if (STREAM) enc.trk_cap = sink_bytes;
+
+    const u32 maxlen = rcx_wave_max(len);
+    // fast path: every lane has a full block and 16-byte loads are aligned
+    const bool full = !STREAM && __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+    const u8* in = src + at;
+
+    DivEntry ahead = divtab[lane];
+    if (full) {
+        U4 cur = *reinterpret_cast<const U4*>(in);
+        for (u32 i0 = 0; i0 < maxlen; i0 += RCX_STAGE) {
+            stage[lane] = ahead;
+            ahead = divtab[i0 + RCX_STAGE + lane]; // table is padded by one stage
+            const u32 jend = (maxlen - i0) < RCX_STAGE ? (maxlen - i0) : RCX_STAGE;
+            for (u32 j0 = 0; j0 < jend; j0 += 16) {
+                const u32 i = i0 + j0;
+                U4 nxt = cur;
+                if (i + 16 < maxlen) nxt = *reinterpret_cast<const U4*>(in + i + 16);
+#pragma unroll
+                for (u32 j = 0; j < 16; ++j) enc.step(tree, rcx_byte_of(cur, j), stage[j0 + j]);
+                cur = nxt;
+            }
+        }
+    } else {
+        for (u32 i0 = 0; i0 < maxlen; i0 += RCX_STAGE) {
+            stage[lane] = ahead;
+            ahead = divtab[i0 + RCX_STAGE + lane];
+            const u32 jend = (maxlen - i0) < RCX_STAGE ? (maxlen - i0) : RCX_STAGE;
+            for (u32 j = 0; j < jend; ++j) {
+                const u32 i = i0 + j;
+                const DivEntry k = stage[j];
+                if (i < len) enc.template step<STREAM>(tree, in[i], k, i);
+            }
+        }
+    }
+
+    if (live) {
+        if (STREAM) {
+            track[0] = enc.trk_fail_at;
+            track[1] = enc.track_flush_fails() ? 1u : 0u;
+        }
+        const u32 bytes = enc.finish();
+        sizes[blk] = enc.overflow ? (u32)slot : bytes;
+        if (enc.overflow) rcx_flag(status, RCX_ST_CAPACITY, blk);
+    }
+}
+
+// ===========================================================================
+// Size prefix: offsets[b] = sum_{i<b} sizes[i], offsets[nblocks] = total.
+// One workgroup of 1024 threads; wave scans via DPP shuffles, 16 wave totals via LDS.
+// ===========================================================================
+__global__ __launch_bounds__(1024) void rcx_scan_sizes_k(const u32* __restrict__ sizes, u64 nblocks, u64* __restrict__ offsets,
+                                                         u64 dst_cap, u32* status)
+{
+    __shared__ u64 wave_total[16];
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 per = (nblocks + 1023) / 1024;
+    const u64 first = (u64)tid * per;
+    const u64 last = (first + per) < nblocks ? (first + per) : nblocks;
+    u64 mine = 0;
+    for (u64 b = first; b < last; ++b) mine += sizes[b];
+    // inclusive wave scan
+    u64 incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        u64 up = (u64)__shfl_up((unsigned long long)incl, o, 64);
+        if ((int)lane >= o) incl += up;
+    }
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads();
+    u64 before = 0;
+    for (u32 w = 0; w < wave; ++w) before += wave_total[w];
+    u64 run = before + incl - mine;
+    for (u64 b = first; b < last; ++b) {
+        offsets[b] = run;
+        run += sizes[b];
+    }
+    if (tid == 1023) {
+        offsets[nblocks] = before + incl;
+        if (before + incl > dst_cap) rcx_flag(status, RCX_ST_CAPACITY, nblocks);
+    }
+}
+
+// ===========================================================================
+// Encode, pass 2: slot b -> dst + offsets[b].  One workgroup per block; the
+// destination is written in aligned 16-byte pieces, the (4-byte aligned) source
+// words are byte-shifted into place.
+// ===========================================================================
+__global__ __launch_bounds__(256) void rcx_scatter_k(const u8* __restrict__ slots, u64 slot, const u32* __restrict__ sizes,
+                                                     const u64* __restrict__ offsets, u8* __restrict__ dst, u64 dst_cap)
+{
+    const u64 blk = blockIdx.x;
+    const u32 size = sizes[blk];
+    const u64 off = offsets[blk];
+    if (off + size > dst_cap) return; // flagged by the scan
+    const u8* s = slots + blk * slot;
+    u8* d = dst + off;
+    const u32 tid = threadIdx.x;
+    u32 head = (u32)((0 - reinterpret_cast<uintptr_t>(d)) & 15u);
+    if (head > size) head = size;
+    if (tid < head) d[tid] = s[tid];
+    const u32 nvec = (size - head) >> 4;
+    const u32 sh = head & 3u;
+    for (u32 v = tid; v < nvec; v += 256) {
+        const u32 sp = head + 16u * v;
+        const u32* w = reinterpret_cast<const u32*>(s + (sp & ~3u));
+        const u32 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+        U4 out;
+        out.x = __builtin_amdgcn_alignbyte(w1, w0, sh);
+        out.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        out.z = __builtin_amdgcn_alignbyte(w3, w2, sh);
+        out.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
+        *reinterpret_cast<U4*>(d + sp) = out;
+    }
+    const u32 done = head + (nvec << 4);
+    if (tid < size - done) d[done + tid] = s[done + tid];
+}
+
+// ===========================================================================
+// Decode
+// ===========================================================================
+// STREAM = the single-stream entry point: one block whose symbol count n the host took from
+// the header (max(declared,1) clipped to the sink); track[0] = first symbol whose normalize
+// ran out of input, or 0xFFFFFFFF.
+template <bool STREAM>
+__global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ comp, const u64* __restrict__ offsets, u64 nblocks,
+                                                         u32 block, u64 n, u8* __restrict__ dst,
+                                                         const DivEntry* __restrict__ divtab, u32* status, u32* track)
+{
+    __shared__ U4 lds[RCX_LDS_U4];
+    const u32 lane = threadIdx.x;
+    const u64 blk = (u64)blockIdx.x * RCX_LANES + lane;
+    bool live = blk < nblocks;
+    const u64 at = live ? blk * (u64)block : 0;
+    u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
+
+    Tree tree{lds + lane};
+    tree.reset();
+    DivEntry* stage = reinterpret_cast<DivEntry*>(lds + RCX_GROUPS * RCX_LANES);
+
+    DecLane dec;
+    u64 stream_len = 0;
+    if (live) {
+        const u64 s0 = offsets[blk], s1 = offsets[blk + 1];
+        stream_len = s1 - s0;
+        if (s1 < s0 || stream_len < (STREAM ? 8u : 9u)) { // cpprcoder.h:878: fewer than 8 bytes cannot even start
+            rcx_flag(status, RCX_ST_CORRUPT, blk);
+            live = false;
+            len = 0;
+        } else {
+            const u32 declared = dec.begin(comp + s0, comp + s1);
+            if (!STREAM && declared != len) { // the layout says len; a header that disagrees is not ours
+                rcx_flag(status, RCX_ST_CORRUPT, blk);
+                live = false;
+                len = 0;
+            }
+        }
+    }
+    if (!live) {
+        dec.low = 0;
+        dec.range = 0x01000000u;
+        dec.win = 0;
+        dec.navail8 = 64;
+        dec.next = comp;
+        dec.end = comp;
+        dec.taken = 0;
+    }
+
+    const u32 maxlen = rcx_wave_max(len);
+    const bool full = !STREAM && __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+    u8* out = dst + at;
+
+    DivEntry ahead = divtab[lane];
+    if (full) {
+        for (u32 i0 = 0; i0 < maxlen; i0 += RCX_STAGE) {
+            stage[lane] = ahead;
+            ahead = divtab[i0 + RCX_STAGE + lane];
+            const u32 jend = (maxlen - i0) < RCX_STAGE ? (maxlen - i0) : RCX_STAGE;
+            for (u32 j0 = 0; j0 < jend; j0 += 16) {
+                const u32 i = i0 + j0;
+                u32 word[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (u32 j = 0; j < 16; ++j) {
+                    const u32 c = dec.step(tree, stage[j0 + j], i + j + 1 == maxlen);
+                    word[j >> 2] |= c << (8 * (j & 3));
+                }
+                U4 o;
+                o.x = word[0];
+                o.y = word[1];
+                o.z = word[2];
+                o.w = word[3];
+                *reinterpret_cast<U4*>(out + i) = o;
+            }
+        }
+    } else {
+        for (u32 i0 = 0; i0 < maxlen; i0 += RCX_STAGE) {
+            stage[lane] = ahead;
+            ahead = divtab[i0 + RCX_STAGE + lane];
+            const u32 jend = (maxlen - i0) < RCX_STAGE ? (maxlen - i0) : RCX_STAGE;
+            for (u32 j = 0; j < jend; ++j) {
+                const u32 i = i0 + j;
+                const DivEntry k = stage[j];
+                if (i < len) out[i] = (u8)dec.template step<STREAM>(tree, k, i + 1 == len, i, stream_len);
+            }
+        }
+    }
+    // the reference returns Status_Pending when normalize runs out of input (cpprcoder.h:901-903)
+    if (STREAM) {
+        if (live) track[0] = dec.short_at;
+    } else if (live && dec.taken > stream_len) {
+        rcx_flag(status, RCX_ST_CORRUPT, blk);
+    }
+}

@@ -1,0 +1,206 @@
+"""ctypes binding of the C ABI in include/rcx.h (cpprcoder_amd/librcx.so).
+
+This is host plumbing for the tests and bench.py: it hands device pointers (torch tensors are
+used only as HBM allocations) and a HIP stream to the native library.  There is no CPU
+fallback: if librcx.so is missing, or there is no GPU when a context is created, it raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librcx.so")
+
+OK, PENDING, ERROR, E_ARG, E_CAPACITY, E_CORRUPT, E_HIP, E_NOMEM = 0, 1, -1, -2, -3, -4, -5, -6
+CODER_ADAPTIVE, CODER_STATIC = 0, 1
+T_ENCODE, T_SCAN, T_SCATTER, T_DECODE, T_COUNT = 0, 1, 2, 3, 4
+MIN_BLOCK, MAX_BLOCK = 16, 1 << 20
+
+# every symbol include/rcx.h declares (tests check that the library exports all of them)
+EXPORTS = (
+    "rcx_version", "rcx_status_string", "rcx_ctx_create", "rcx_ctx_destroy", "rcx_ctx_reserve", "rcx_ctx_sync_status",
+    "rcx_block_count", "rcx_block_bound", "rcx_encode_bound", "rcx_encode_blocks_device", "rcx_decode_blocks_device",
+    "rcx_encode_blocks", "rcx_decode_blocks", "rcx_stream_encode", "rcx_stream_decode", "rcx_ctx_set_timing",
+    "rcx_ctx_get_timing",
+)
+
+
+class RcxError(RuntimeError):
+    def __init__(self, status: int, where: str):
+        self.status = status
+        super().__init__(f"{where}: rcx status {status} ({status_string(status)})")
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -m cpprcoder_amd.build` "
+                              "(there is no CPU fallback for the HIP path)")
+        L = C.CDLL(LIB_PATH)
+        vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+        L.rcx_version.restype = i32
+        L.rcx_status_string.restype, L.rcx_status_string.argtypes = C.c_char_p, [i32]
+        L.rcx_ctx_create.restype, L.rcx_ctx_create.argtypes = i32, [i32, C.POINTER(vp)]
+        L.rcx_ctx_destroy.restype, L.rcx_ctx_destroy.argtypes = None, [vp]
+        L.rcx_ctx_reserve.restype, L.rcx_ctx_reserve.argtypes = i32, [vp, u64, u32]
+        L.rcx_ctx_sync_status.restype, L.rcx_ctx_sync_status.argtypes = i32, [vp, vp, C.POINTER(u64)]
+        L.rcx_block_count.restype, L.rcx_block_count.argtypes = u64, [u64, u32]
+        L.rcx_block_bound.restype, L.rcx_block_bound.argtypes = u64, [u32]
+        L.rcx_encode_bound.restype, L.rcx_encode_bound.argtypes = u64, [u64, u32]
+        L.rcx_encode_blocks_device.restype = i32
+        L.rcx_encode_blocks_device.argtypes = [vp, i32, vp, u64, u32, vp, u64, vp, vp]
+        L.rcx_decode_blocks_device.restype = i32
+        L.rcx_decode_blocks_device.argtypes = [vp, i32, vp, u64, vp, u64, u32, u64, vp, vp]
+        L.rcx_encode_blocks.restype = i32
+        L.rcx_encode_blocks.argtypes = [vp, i32, vp, u64, u32, vp, u64, C.POINTER(u64), vp]
+        L.rcx_decode_blocks.restype = i32
+        L.rcx_decode_blocks.argtypes = [vp, i32, vp, u64, vp, u64, u32, vp, u64, C.POINTER(u64)]
+        L.rcx_stream_encode.restype = i32
+        L.rcx_stream_encode.argtypes = [vp, i32, vp, u32, vp, u64, C.POINTER(u64), C.POINTER(u32)]
+        L.rcx_stream_decode.restype = i32
+        L.rcx_stream_decode.argtypes = [vp, i32, vp, u64, vp, u64, C.POINTER(u64), C.POINTER(u32)]
+        L.rcx_ctx_set_timing.restype, L.rcx_ctx_set_timing.argtypes = i32, [vp, i32]
+        L.rcx_ctx_get_timing.restype, L.rcx_ctx_get_timing.argtypes = i32, [vp, C.POINTER(C.c_double), C.POINTER(u64), i32]
+        _lib = L
+    return _lib
+
+
+def status_string(status: int) -> str:
+    return lib().rcx_status_string(status).decode()
+
+
+def block_count(n: int, block: int) -> int:
+    return int(lib().rcx_block_count(n, block))
+
+
+def block_bound(block: int) -> int:
+    return int(lib().rcx_block_bound(block))
+
+
+def encode_bound(n: int, block: int) -> int:
+    return int(lib().rcx_encode_bound(n, block))
+
+
+def _check(status: int, where: str) -> None:
+    if status != OK:
+        raise RcxError(status, where)
+
+
+def _np_u8(a) -> np.ndarray:
+    if isinstance(a, (bytes, bytearray, memoryview)):
+        return np.frombuffer(bytes(a), dtype=np.uint8)
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+class Context:
+    """One rcx_ctx (device scratch of one GPU).  Single-threaded, like a reference coder object."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        _check(lib().rcx_ctx_create(device, C.byref(self._h)), "rcx_ctx_create")
+        self.device = device
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().rcx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reserve(self, n: int, block: int) -> None:
+        _check(lib().rcx_ctx_reserve(self._h, n, block), "rcx_ctx_reserve")
+
+    # ---- device pointers (torch tensors as HBM) ---------------------------
+    @staticmethod
+    def _stream_handle(stream) -> int:
+        if stream is None:
+            import torch
+            return torch.cuda.current_stream().cuda_stream
+        return getattr(stream, "cuda_stream", stream)
+
+    def encode_blocks_device(self, src, block: int, dst, offsets, coder: int = CODER_ADAPTIVE, stream=None) -> None:
+        """src: uint8 cuda tensor; dst: uint8 cuda tensor (>= encode_bound); offsets: int64 cuda tensor [nblocks+1]."""
+        n = src.numel()
+        assert offsets.numel() >= block_count(n, block) + 1
+        st = lib().rcx_encode_blocks_device(self._h, coder, src.data_ptr(), n, block, dst.data_ptr(), dst.numel(),
+                                            offsets.data_ptr(), self._stream_handle(stream))
+        _check(st, "rcx_encode_blocks_device")
+
+    def decode_blocks_device(self, comp, comp_size: int, offsets, n: int, block: int, out,
+                             coder: int = CODER_ADAPTIVE, stream=None) -> None:
+        nblocks = block_count(n, block)
+        st = lib().rcx_decode_blocks_device(self._h, coder, comp.data_ptr(), comp_size, offsets.data_ptr(), nblocks, block,
+                                            n, out.data_ptr(), self._stream_handle(stream))
+        _check(st, "rcx_decode_blocks_device")
+
+    def sync_status(self, stream=None, raise_on_error: bool = True):
+        bad = C.c_uint64()
+        st = lib().rcx_ctx_sync_status(self._h, self._stream_handle(stream), C.byref(bad))
+        if st != OK and raise_on_error:
+            raise RcxError(st, f"block {bad.value}")
+        return st, bad.value
+
+    # ---- host buffers ------------------------------------------------------
+    def encode_blocks(self, data, block: int, coder: int = CODER_ADAPTIVE):
+        """-> (payload uint8[total], offsets uint64[nblocks+1])"""
+        src = _np_u8(data)
+        n = len(src)
+        nblocks = block_count(n, block)
+        dst = np.zeros(encode_bound(n, block), dtype=np.uint8)
+        offsets = np.zeros(nblocks + 1, dtype=np.uint64)
+        size = C.c_uint64()
+        st = lib().rcx_encode_blocks(self._h, coder, src.ctypes.data, n, block, dst.ctypes.data, len(dst), C.byref(size),
+                                     offsets.ctypes.data)
+        _check(st, "rcx_encode_blocks")
+        return dst[: size.value].copy(), offsets
+
+    def decode_blocks(self, payload, offsets, block: int, capacity: int | None = None, coder: int = CODER_ADAPTIVE):
+        comp = _np_u8(payload)
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nblocks = len(offs) - 1
+        cap = nblocks * block if capacity is None else capacity
+        out = np.zeros(max(cap, 1), dtype=np.uint8)
+        size = C.c_uint64()
+        st = lib().rcx_decode_blocks(self._h, coder, comp.ctypes.data, len(comp), offs.ctypes.data, nblocks, block,
+                                     out.ctypes.data, cap, C.byref(size))
+        _check(st, "rcx_decode_blocks")
+        return out[: size.value].copy()
+
+    # ---- single streams (reference semantics, used by the C++ facade) ------
+    def stream_encode(self, data, sink_capacity: int | None = None, coder: int = CODER_ADAPTIVE):
+        """-> (status, request_size, stream bytes)"""
+        src = _np_u8(data)
+        cap = (len(src) + len(src) // 32 + 1024) if sink_capacity is None else sink_capacity
+        dst = np.zeros(max(cap, 16) + 64, dtype=np.uint8)
+        size, req = C.c_uint64(), C.c_uint32()
+        st = lib().rcx_stream_encode(self._h, coder, src.ctypes.data, len(src), dst.ctypes.data, cap, C.byref(size), C.byref(req))
+        return st, req.value, bytes(dst[: size.value])
+
+    def stream_decode(self, comp, sink_capacity: int, coder: int = CODER_ADAPTIVE):
+        src = _np_u8(comp)
+        dst = np.zeros(max(sink_capacity, 16) + 64, dtype=np.uint8)
+        size, req = C.c_uint64(), C.c_uint32()
+        st = lib().rcx_stream_decode(self._h, coder, src.ctypes.data, len(src), dst.ctypes.data, sink_capacity, C.byref(size), C.byref(req))
+        return st, req.value, bytes(dst[: size.value])
+
+    # ---- per-kernel device time -------------------------------------------
+    def set_timing(self, enabled: bool) -> None:
+        _check(lib().rcx_ctx_set_timing(self._h, int(enabled)), "rcx_ctx_set_timing")
+
+    def get_timing(self, reset: bool = True):
+        ms = (C.c_double * T_COUNT)()
+        launches = (C.c_uint64 * T_COUNT)()
+        _check(lib().rcx_ctx_get_timing(self._h, ms, launches, int(reset)), "rcx_ctx_get_timing")
+        names = ("encode", "scan", "scatter", "decode")
+        return {names[i]: {"ms": ms[i], "launches": int(launches[i])} for i in range(T_COUNT)}

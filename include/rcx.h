@@ -1,0 +1,147 @@
+/*
+ * rcx.h -- C ABI of the MI355X-native many-block range coder.
+ *
+ * The reference (taqu/cpprcoder) is a header-only C++ template library with no
+ * FFI of its own; its boundary is the class API in cpprcoder.h:
+ *     bool   AdaptiveRangeEncoder<T>::initialize(T&, u32)      cpprcoder.h:636, 678-695
+ *     Result AdaptiveRangeEncoder<T>::encode(s32, const u8*)   cpprcoder.h:637, 697-720
+ *     bool   AdaptiveRangeDecoder<T>::initialize(T&)           cpprcoder.h:819, 859-870
+ *     Result AdaptiveRangeDecoder<T>::decode(s32, const u8*)   cpprcoder.h:820, 872-924
+ *     bool   RangeEncoder<T>::encode / decode                  cpprcoder.h:336-337, 375-519
+ *     enum Status / struct Result                              cpprcoder.h:112-123
+ * and it is driven per whole buffer by test/main.cpp:321-344.  This header is
+ * the plain-C surface a binding (cgo, JNI, ctypes, N-API ...) or the C++ facade
+ * include/cpprcoder_amd/cpprcoder.h sits on.  Every entry point names the
+ * reference interface it replaces.
+ *
+ * Data model.  A buffer of n bytes is cut into blocks of `block` bytes (the last
+ * one may be short).  Block b is coded by a fresh coder exactly as the reference
+ * codes a whole file: the per-block stream is byte-identical to
+ *     initialize(stream, len_b); encode(len_b, src + b*block);
+ * i.e. [u32 LE len_b][0x00][payload...][u32 BE low].  The streams are stored
+ * back to back ("compacted"); offsets[b] .. offsets[b+1] delimits block b and
+ * offsets[nblocks] is the total size.
+ *
+ * All functions return an rcx status (0 = success, 1 = pending, negative = error)
+ * and never throw, abort or print.  Pointers named d_* are device (HBM) pointers
+ * of the context's GPU; all others are host pointers.  `stream` is a hipStream_t
+ * passed as void* (NULL = the default stream).  The *_device calls only enqueue
+ * work; block-level failures (slot overflow, corrupt input) are latched on the
+ * device and read with rcx_ctx_sync_status().
+ */
+#ifndef RCX_H_
+#define RCX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCX_VERSION 100 /* 0.1.0 */
+
+/* Status codes.  0 / 1 / -1 are the reference's Status enum (cpprcoder.h:112-117). */
+enum {
+    RCX_OK = 0,          /* Status_Success */
+    RCX_PENDING = 1,     /* Status_Pending: output sink full or input exhausted */
+    RCX_ERROR = -1,      /* Status_Error */
+    RCX_E_ARG = -2,      /* bad argument (null pointer, block size out of range ...) */
+    RCX_E_CAPACITY = -3, /* destination too small / a block outgrew its scratch slot */
+    RCX_E_CORRUPT = -4,  /* a block's stream is truncated or its header disagrees with the layout */
+    RCX_E_HIP = -5,      /* HIP runtime error, or no usable MI355X */
+    RCX_E_NOMEM = -6     /* device or host allocation failed */
+};
+
+/* Which coder a call uses. */
+enum {
+    RCX_CODER_ADAPTIVE = 0, /* AdaptiveRangeEncoder/Decoder, cpprcoder.h:626-940 */
+    RCX_CODER_STATIC = 1    /* RangeEncoder (two-pass, 516-byte table header), cpprcoder.h:321-619 */
+};
+
+#define RCX_MIN_BLOCK 16u
+#define RCX_MAX_BLOCK (1u << 20) /* the GPU kernels never need the table halving of cpprcoder.h:1138 below 2^24-256 symbols */
+
+typedef struct rcx_ctx rcx_ctx;
+
+int rcx_version(void);
+const char* rcx_status_string(int status);
+
+/* A context owns the device scratch (per-block slots, size table, divisor table)
+ * of one GPU.  It is single-threaded; use one context per thread / stream. */
+int rcx_ctx_create(int device, rcx_ctx** out);
+void rcx_ctx_destroy(rcx_ctx* ctx);
+/* Pre-allocate scratch for buffers up to n bytes at this block size (otherwise the
+ * first call that needs more allocates, which is not allowed under graph capture). */
+int rcx_ctx_reserve(rcx_ctx* ctx, uint64_t n, uint32_t block);
+/* Wait for `stream`, then return and clear the latched device-side status:
+ * RCX_OK, RCX_E_CAPACITY or RCX_E_CORRUPT; *first_bad_block (optional) gets the
+ * lowest failing block index. */
+int rcx_ctx_sync_status(rcx_ctx* ctx, void* stream, uint64_t* first_bad_block);
+
+/* Geometry helpers (pure functions). */
+uint64_t rcx_block_count(uint64_t n, uint32_t block);   /* ceil(n / block) */
+uint64_t rcx_block_bound(uint32_t block);               /* bytes reserved for one block's stream */
+uint64_t rcx_encode_bound(uint64_t n, uint32_t block);  /* safe dst_cap for the compacted streams */
+
+/*
+ * Encode n bytes as independent blocks on the GPU.
+ * Replaces, per block: AdaptiveRangeEncoder<T>::initialize + encode (cpprcoder.h:678-720)
+ * or RangeEncoder<T>::encode (cpprcoder.h:375-458), and the MemoryStream sink
+ * (cpprcoder.h:1031-1054) as the output writer.
+ *   d_src      n input bytes
+ *   d_dst      compacted streams, capacity dst_cap (>= rcx_encode_bound(n, block) is always enough)
+ *   d_offsets  nblocks+1 u64, exclusive prefix of the per-block stream sizes (written)
+ */
+int rcx_encode_blocks_device(rcx_ctx* ctx, int coder, const void* d_src, uint64_t n, uint32_t block,
+                             void* d_dst, uint64_t dst_cap, uint64_t* d_offsets, void* stream);
+
+/*
+ * Decode blocks produced by rcx_encode_blocks_device (or by the reference, block by block).
+ * Replaces, per block: AdaptiveRangeDecoder<T>::initialize + decode (cpprcoder.h:859-924)
+ * or RangeEncoder<T>::decode (cpprcoder.h:460-519).
+ *   d_comp     the compacted streams, comp_size bytes
+ *   d_offsets  nblocks+1 u64 as written by the encoder
+ *   n          total decoded size; block b must declare min(block, n - b*block) bytes
+ *   d_dst      n output bytes
+ */
+int rcx_decode_blocks_device(rcx_ctx* ctx, int coder, const void* d_comp, uint64_t comp_size,
+                             const uint64_t* d_offsets, uint64_t nblocks, uint32_t block,
+                             uint64_t n, void* d_dst, void* stream);
+
+/* Host-buffer variants: copy in, run the device path, copy out, synchronise.
+ * offsets may be NULL for encode when only the payload is wanted. */
+int rcx_encode_blocks(rcx_ctx* ctx, int coder, const uint8_t* src, uint64_t n, uint32_t block,
+                      uint8_t* dst, uint64_t dst_cap, uint64_t* dst_size, uint64_t* offsets);
+int rcx_decode_blocks(rcx_ctx* ctx, int coder, const uint8_t* comp, uint64_t comp_size,
+                      const uint64_t* offsets, uint64_t nblocks, uint32_t block,
+                      uint8_t* dst, uint64_t dst_cap, uint64_t* dst_size);
+
+/*
+ * Single-stream calls with the reference's exact stream semantics, used by the
+ * C++ facade: one stream = one block of any size 0 .. RCX_MAX_BLOCK.
+ *   rcx_stream_encode == initialize(sink, n); encode(n, src)  into a sink whose
+ *       writeByte capacity is sink_capacity (MemoryStream rounds it up to 16,
+ *       cpprcoder.h:975): returns RCX_OK, or RCX_PENDING with *request_size set as
+ *       cpprcoder.h:708-711 does when the sink fills (dst then holds the bytes
+ *       written so far).
+ *   rcx_stream_decode == initialize(sink); decode(comp_size, comp): RCX_OK,
+ *       RCX_PENDING (+ request_size) for short input or a full sink, including the
+ *       reference's quirk that a stream declaring 0 bytes yields one byte (cpprcoder.h:912).
+ */
+int rcx_stream_encode(rcx_ctx* ctx, int coder, const uint8_t* src, uint32_t n,
+                      uint8_t* dst, uint64_t sink_capacity, uint64_t* dst_size, uint32_t* request_size);
+int rcx_stream_decode(rcx_ctx* ctx, int coder, const uint8_t* comp, uint64_t comp_size,
+                      uint8_t* dst, uint64_t sink_capacity, uint64_t* dst_size, uint32_t* request_size);
+
+/* Per-kernel device time of the calls made since the last reset, in milliseconds,
+ * measured with HIP events on the stream the kernels ran on (off by default). */
+enum { RCX_T_ENCODE = 0, RCX_T_SCAN = 1, RCX_T_SCATTER = 2, RCX_T_DECODE = 3, RCX_T_COUNT = 4 };
+int rcx_ctx_set_timing(rcx_ctx* ctx, int enabled);
+/* Synchronises the events; ms[RCX_T_COUNT] = summed durations, launches[RCX_T_COUNT] = launch counts. */
+int rcx_ctx_get_timing(rcx_ctx* ctx, double* ms, uint64_t* launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCX_H_ */

@@ -1,0 +1,140 @@
+// lane_sim.cpp -- host-side lane simulator (TEST TOOLING, not part of librcx.so).
+//
+// Compiles cpprcoder_amd/csrc/rcx_lane.hpp -- the very code the gfx950 kernels run per
+// lane -- with g++ and drives it block by block, so that the CPU test suite can check
+// the device arithmetic (divisor table, eager carry, register window, tree model)
+// against the oracle without a GPU.  Lane `lane` of a 64-lane LDS image is used so that
+// the interleaved layout is exercised too.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../cpprcoder_amd/csrc/rcx_divtab.hpp"
+
+uint64_t rcx_sim_counters[4] = {0, 0, 0, 0};
+
+extern "C" {
+
+void sim_counters(uint64_t* out, int reset)
+{
+    for (int i = 0; i < 4; ++i) {
+        out[i] = rcx_sim_counters[i];
+        if (reset) rcx_sim_counters[i] = 0;
+    }
+}
+
+// exhaustive-ish check of the divisor entries: returns the first failing divisor or 0
+uint32_t sim_check_divtab(uint32_t d_first, uint32_t d_last)
+{
+    for (uint32_t d = d_first; d <= d_last; ++d) {
+        DivEntry e = rcx_make_div_entry(d);
+        const uint64_t probes[] = {0, 1, d - 1, d, d + 1, 2ull * d - 1, 2ull * d, 0x00FFFFFFull, 0x01000000ull, 0x7FFFFFFFull,
+                                   0x80000000ull, 0xFFFFFF00ull, 0xFFFFFFFEull, 0xFFFFFFFFull};
+        for (uint64_t n : probes)
+            if (rcx_div((u32)n, e) != (u32)n / d) return d;
+        // multiples of d around the top of the range, where the magic is most stressed
+        uint64_t q = 0xFFFFFFFFull / d;
+        for (uint64_t k = 0; k < 64 && k <= q; ++k) {
+            uint64_t m = (q - k) * d;
+            for (int delta = -1; delta <= 1; ++delta) {
+                uint64_t n = m + delta;
+                if (n > 0xFFFFFFFFull) continue;
+                if (rcx_div((u32)n, e) != (u32)(n / d)) return d;
+            }
+        }
+        uint64_t x = 0x9E3779B97F4A7C15ull * d;
+        for (int k = 0; k < 64; ++k) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            u32 n = (u32)(x >> 16);
+            if (rcx_div(n, e) != n / d) return d;
+        }
+    }
+    return 0;
+}
+
+int sim_encode_blocks(const uint8_t* src, uint64_t n, uint32_t block, uint8_t* slots, uint64_t slot, uint32_t* sizes, uint32_t lane)
+{
+    std::vector<U4> lds((RCX_GROUPS + 1) * RCX_LANES);
+    std::vector<DivEntry> tab(block + 2 * RCX_STAGE);
+    for (size_t i = 0; i < tab.size(); ++i) tab[i] = rcx_make_div_entry((u32)(256 + i));
+    uint64_t nblocks = (n + block - 1) / block;
+    int overflow = 0;
+    for (uint64_t b = 0; b < nblocks; ++b) {
+        uint64_t at = b * block;
+        uint32_t len = (uint32_t)((n - at) < block ? (n - at) : block);
+        Tree tree{lds.data() + lane};
+        tree.reset();
+        EncLane e;
+        e.begin(slots + b * slot, (u32)slot, len);
+        for (uint32_t i = 0; i < len; ++i) e.step(tree, src[at + i], tab[i]);
+        sizes[b] = e.finish();
+        overflow |= (int)e.overflow;
+    }
+    return overflow;
+}
+
+// One stream into a sink of `sink16` bytes (already rounded as MemoryStream does): replays the
+// TRACK pass of rcx_stream_encode.  out[0] = failing symbol or 0xFFFFFFFF, out[1] = flush fails,
+// out[2] = full stream size.
+void sim_stream_encode_track(const uint8_t* src, uint32_t n, uint64_t sink16, uint8_t* slot, uint64_t slot_bytes, uint32_t* out)
+{
+    std::vector<U4> lds((RCX_GROUPS + 1) * RCX_LANES);
+    Tree tree{lds.data() + 3};
+    tree.reset();
+    EncLane e;
+    e.begin(slot, (u32)slot_bytes, n);
+    e.trk_cap = (u32)(sink16 - 4);
+    for (uint32_t i = 0; i < n; ++i) e.step<true>(tree, src[i], rcx_make_div_entry(256 + i), i);
+    out[0] = e.trk_fail_at;
+    out[1] = e.track_flush_fails() ? 1u : 0u;
+    out[2] = e.finish();
+}
+
+// One stream decoded for `count` symbols; returns short_at.
+uint32_t sim_stream_decode_track(const uint8_t* comp, uint64_t comp_size, uint32_t count, uint8_t* dst)
+{
+    std::vector<U4> lds((RCX_GROUPS + 1) * RCX_LANES);
+    Tree tree{lds.data() + 9};
+    tree.reset();
+    std::vector<uint8_t> pad(comp_size + 32);
+    uint8_t* base = pad.data();
+    while (((uintptr_t)base & 3) != 0) ++base;
+    base += 4;
+    memcpy(base, comp, comp_size);
+    DecLane d;
+    d.begin(base, base + comp_size);
+    for (uint32_t i = 0; i < count; ++i) dst[i] = (uint8_t)d.step<true>(tree, rcx_make_div_entry(256 + i), i + 1 == count, i, comp_size);
+    return d.short_at;
+}
+
+// comp/offsets as the encoder's compacted output.  Returns 0, or 1 + index of the first bad block.
+uint64_t sim_decode_blocks(const uint8_t* comp, const uint64_t* offsets, uint64_t nblocks, uint32_t block, uint64_t n, uint8_t* dst, uint32_t lane)
+{
+    std::vector<U4> lds((RCX_GROUPS + 1) * RCX_LANES);
+    std::vector<DivEntry> tab(block + 2 * RCX_STAGE);
+    for (size_t i = 0; i < tab.size(); ++i) tab[i] = rcx_make_div_entry((u32)(256 + i));
+    for (uint64_t b = 0; b < nblocks; ++b) {
+        uint64_t at = b * block;
+        uint32_t len = (uint32_t)((n - at) < block ? (n - at) : block);
+        uint64_t s0 = offsets[b], s1 = offsets[b + 1];
+        if (s1 < s0 || s1 - s0 < 9) return b + 1;
+        Tree tree{lds.data() + lane};
+        tree.reset();
+        DecLane d;
+        // the device code loads aligned dwords that may start before / end after the stream:
+        // give it a padded private copy at the same alignment
+        std::vector<uint8_t> pad(s1 - s0 + 16);
+        uint32_t skew = (uint32_t)(s0 & 3);
+        uint8_t* base = pad.data();
+        while (((uintptr_t)base & 3) != 0) ++base;
+        base += skew + 4;
+        memcpy(base, comp + s0, s1 - s0);
+        u32 declared = d.begin(base, base + (s1 - s0));
+        if (declared != len) return b + 1;
+        for (uint32_t i = 0; i < len; ++i) dst[at + i] = (uint8_t)d.step(tree, tab[i], i + 1 == len);
+        if (d.taken > s1 - s0) return b + 1;
+    }
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,250 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle and the golden vectors.
+
+Bit-exact bar: every block's stream must equal what the reference emits for that block
+(cpprcoder.h:678-802), and decode(encode(x)) == x (the reference harness's own check,
+test/main.cpp:357-361).  Nothing here reads /root/reference.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from cpprcoder_amd import workloads
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from cpprcoder_amd import rcx
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    c = rcx.Context(0)
+    yield c
+    c.close()
+
+
+def gpu_encode(ctx, data, block, src_offset=0):
+    """-> (payload np.uint8, offsets np.uint64) through the device-pointer entry points."""
+    from cpprcoder_amd import rcx
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    n = len(data)
+    buf = torch.zeros(n + src_offset + 16, dtype=torch.uint8, device="cuda")
+    buf[src_offset:src_offset + n] = torch.from_numpy(data).cuda()
+    src = buf[src_offset:src_offset + n]
+    nblocks = rcx.block_count(n, block)
+    dst = torch.zeros(rcx.encode_bound(n, block), dtype=torch.uint8, device="cuda")
+    offs = torch.zeros(nblocks + 1, dtype=torch.int64, device="cuda")
+    ctx.encode_blocks_device(src, block, dst, offs)
+    ctx.sync_status()
+    offsets = offs.cpu().numpy().astype(np.uint64)
+    return dst[: int(offsets[-1])].cpu().numpy(), offsets, (dst, offs)
+
+
+def gpu_decode(ctx, payload, offsets, n, block, dst_offset=0, comp_offset=0):
+    comp = torch.zeros(len(payload) + comp_offset + 16, dtype=torch.uint8, device="cuda")
+    comp[comp_offset:comp_offset + len(payload)] = torch.from_numpy(np.ascontiguousarray(payload)).cuda()
+    offs = torch.from_numpy(np.asarray(offsets).astype(np.int64)).cuda()
+    out = torch.zeros(n + dst_offset + 16, dtype=torch.uint8, device="cuda")
+    ctx.decode_blocks_device(comp[comp_offset:], len(payload), offs, n, block, out[dst_offset:])
+    st, bad = ctx.sync_status(raise_on_error=False)
+    return out[dst_offset:dst_offset + n].cpu().numpy(), st, bad
+
+
+def assert_same_blocks(payload, offsets, slots, sizes):
+    assert np.array_equal(np.diff(offsets.astype(np.int64)), sizes.astype(np.int64)), "per-block sizes differ"
+    for b in range(len(sizes)):
+        got = payload[int(offsets[b]): int(offsets[b + 1])]
+        assert np.array_equal(got, slots[b, : int(sizes[b])]), f"block {b} differs"
+
+
+def test_golden_block_tables(ctx, golden):
+    for t in golden["blocks"]:
+        if t["coder"] != "adaptive":
+            continue
+        data = workloads.by_name(t["workload"], t["n"], t["seed"])
+        assert hashlib.sha256(data.tobytes()).hexdigest() == t["input_sha256"]
+        payload, offsets, _ = gpu_encode(ctx, data, t["block"])
+        assert [int(x) for x in np.diff(offsets.astype(np.int64))] == t["sizes"], (t["workload"], t["block"])
+        fnv = ["%016x" % oracle_lib.fnv1a64(payload[int(offsets[b]): int(offsets[b + 1])]) for b in range(len(t["sizes"]))]
+        assert fnv == t["fnv1a64"], (t["workload"], t["block"])
+        assert int(offsets[-1]) == t["total"]
+        back, st, _ = gpu_decode(ctx, payload, offsets, t["n"], t["block"])
+        assert st == 0 and np.array_equal(back, data)
+
+
+@pytest.mark.parametrize("block", [16, 48, 100, 1000, 4096, 16384, 65536, 65552, 262144, 1 << 20])
+def test_ragged_sizes_match_oracle(ctx, oracle, block):
+    rs = np.random.RandomState(block)
+    for trial in range(3):
+        nblocks = int(rs.randint(1, 200 if block <= 4096 else (70 if block <= 65552 else 5)))
+        n = block * (nblocks - 1) + int(rs.randint(1, block + 1))  # last block ragged, may be 1 byte
+        wl = ("uniform", "zipf", "runs", "canterbury")[trial % 4] if trial else "uniform"
+        data = workloads.by_name(wl, n, 1000 + trial)
+        slots, sizes = oracle.encode_blocks(data, block, threads=8)
+        off = (0, 1, 5)[trial]  # the source need not be 16-byte aligned
+        payload, offsets, _ = gpu_encode(ctx, data, block, src_offset=off)
+        assert_same_blocks(payload, offsets, slots, sizes)
+        back, st, _ = gpu_decode(ctx, payload, offsets, n, block, dst_offset=off, comp_offset=(0, 3, 2)[trial])
+        assert st == 0 and np.array_equal(back, data)
+
+
+def test_edge_inputs(ctx, oracle):
+    files = workloads.canterbury_files()
+    cases = [
+        (np.full(300000, 255, np.uint8), 65536), (np.zeros(70000, np.uint8), 65536), (np.full(1 << 20, 65, np.uint8), 1 << 20),
+        (np.arange(256, dtype=np.uint8).repeat(3), 768), (np.frombuffer(files["ptt5"], np.uint8), 65536),
+        (np.frombuffer(files["kennedy.xls"], np.uint8), 1 << 20), (np.array([7], np.uint8), 65536),
+        (np.frombuffer(files["alice29.txt"], np.uint8), 1 << 20),  # BASELINE config 1: alice29 as ONE block
+    ]
+    for data, block in cases:
+        slots, sizes = oracle.encode_blocks(data, block, threads=8)
+        payload, offsets, _ = gpu_encode(ctx, data, block)
+        assert_same_blocks(payload, offsets, slots, sizes)
+        back, st, _ = gpu_decode(ctx, payload, offsets, len(data), block)
+        assert st == 0 and np.array_equal(back, data)
+    # alice29 single block: the README's pinned size (README.md:36, 0.573000 * 152089)
+    data = np.frombuffer(files["alice29.txt"], np.uint8)
+    payload, offsets, _ = gpu_encode(ctx, data, 1 << 20)
+    assert len(payload) == 87147
+
+
+def test_empty_input(ctx):
+    from cpprcoder_amd import rcx
+    src = torch.zeros(16, dtype=torch.uint8, device="cuda")[:0]
+    dst = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    offs = torch.full((1,), 77, dtype=torch.int64, device="cuda")
+    ctx.encode_blocks_device(src, 65536, dst, offs)
+    ctx.sync_status()
+    assert int(offs[0]) == 0
+    payload, offsets = ctx.encode_blocks(np.zeros(0, np.uint8), 65536)
+    assert len(payload) == 0 and list(offsets) == [0]
+    assert len(ctx.decode_blocks(payload, offsets, 65536)) == 0
+
+
+def test_gpu_decodes_reference_streams_and_back(ctx, oracle):
+    # streams produced by the CPU coder decode on the GPU, and GPU streams decode on the CPU coder
+    data = workloads.canterbury_tiled(3_000_000)
+    block = 65536
+    slots, sizes = oracle.encode_blocks(data, block, threads=8)
+    payload, offsets = oracle.compact(slots, sizes)
+    back, st, _ = gpu_decode(ctx, payload, offsets, len(data), block)
+    assert st == 0 and np.array_equal(back, data)
+    gp, go, _ = gpu_encode(ctx, data, block)
+    gslots = np.zeros_like(slots)
+    for b in range(len(sizes)):
+        gslots[b, : int(sizes[b])] = gp[int(go[b]): int(go[b + 1])]
+    cpu_back, ok = oracle.decode_blocks(gslots, sizes, block, len(data), threads=8)
+    assert ok and np.array_equal(cpu_back, data)
+
+
+def test_host_buffer_entry_points(ctx, oracle):
+    data = workloads.zipf(1_000_003, 4)
+    payload, offsets = ctx.encode_blocks(data, 65536)
+    slots, sizes = oracle.encode_blocks(data, 65536, threads=8)
+    assert_same_blocks(payload, offsets, slots, sizes)
+    assert np.array_equal(ctx.decode_blocks(payload, offsets, 65536), data)
+
+
+def test_errors_are_reported_not_fatal(ctx, oracle):
+    from cpprcoder_amd import rcx
+    data = workloads.uniform(65536 * 4 + 100, 3)
+    payload, offsets, _ = gpu_encode(ctx, data, 65536)
+    # header of block 2 disagrees with the layout -> corrupt, first bad block = 2
+    bad = payload.copy()
+    bad[int(offsets[2])] ^= 1
+    _, st, blk = gpu_decode(ctx, bad, offsets, len(data), 65536)
+    assert st == rcx.E_CORRUPT and blk == 2
+    # truncated stream: the last block loses its tail
+    cut = offsets.copy()
+    cut[-1] -= 40
+    _, st, blk = gpu_decode(ctx, payload[: int(cut[-1])], cut, len(data), 65536)
+    assert st == rcx.E_CORRUPT and blk == 4
+    # the context is still usable afterwards
+    back, st, _ = gpu_decode(ctx, payload, offsets, len(data), 65536)
+    assert st == 0 and np.array_equal(back, data)
+    # destination too small for the compacted streams
+    src = torch.from_numpy(data).cuda()
+    dst = torch.zeros(100000, dtype=torch.uint8, device="cuda")
+    offs = torch.zeros(6, dtype=torch.int64, device="cuda")
+    ctx.encode_blocks_device(src, 65536, dst, offs)
+    st, _ = ctx.sync_status(raise_on_error=False)
+    assert st == rcx.E_CAPACITY
+    with pytest.raises(rcx.RcxError):
+        ctx.encode_blocks_device(src, 8, dst, offs)  # block size out of range
+    with pytest.raises(rcx.RcxError):
+        ctx.encode_blocks_device(src, (1 << 20) + 16, dst, offs)
+
+
+def test_single_stream_semantics(ctx, oracle, golden):
+    """rcx_stream_encode / rcx_stream_decode == the reference's initialize+encode / initialize+decode
+    on a MemoryStream of the given capacity (cpprcoder.h:678-720, 859-924, 1047-1054)."""
+    for k in golden["kat"]["kat"]:
+        v = bytes.fromhex(k["input_hex"])
+        st, rq, out = ctx.stream_encode(v)
+        assert (st, rq, out.hex()) == (0, 0, k["adaptive_hex"])
+        st, rq, back = ctx.stream_decode(out, max(len(v), 16))
+        assert st == 0 and back == (v if v else b"\x00")  # cpprcoder.h:912 quirk for the empty stream
+    u64k = workloads.uniform(65536, 12345)
+    st, rq, out = ctx.stream_encode(u64k, sink_capacity=65536)  # {Pending, 112}
+    pin = golden["kat"]["pins"]["overflow_uniform64k_into_65536"]
+    assert [st, rq] == pin["status"] == [1, 112] and len(out) == pin["size"]
+    assert hashlib.sha256(out).hexdigest() == pin["prefix_sha256"]
+    rs = np.random.RandomState(77)
+    for _ in range(25):
+        n = int(rs.randint(1, 4000))
+        data = workloads.by_name(("uniform", "zipf", "runs")[int(rs.randint(3))], n, int(rs.randint(1 << 30)))
+        full = oracle.adaptive_encode(data)[2]
+        for cap in (int(rs.randint(16, full + 32)), max(16, full - int(rs.randint(0, 12)))):
+            (rst, rrq), rout, rsize = oracle.adaptive_encode(data, sink_capacity=cap)
+            st, rq, out = ctx.stream_encode(data, sink_capacity=cap)
+            assert (st, rq, len(out)) == (rst, rrq, rsize) and out[: len(rout)] == rout
+    pins = golden["kat"]["pins"]
+    st, rq, out = ctx.stream_decode(b"\x01\x00\x00", 16)
+    assert [st, rq] == pins["decode_short_input"]["status"] and out == b""
+    for key in ("decode_junk_64", "decode_allff_64"):
+        st, rq, out = ctx.stream_decode(bytes.fromhex(pins[key]["input_hex"]), 64)
+        assert [st, rq] == pins[key]["status"] and out.hex() == pins[key]["out_hex"]
+    comp = oracle.adaptive_encode(u64k[:3000])[1]
+    st, rq, out = ctx.stream_decode(comp[:1500], 3000)
+    assert [st, rq] == pins["decode_truncated"]["status"] and len(out) == pins["decode_truncated"]["size"]
+    assert hashlib.sha256(out).hexdigest() == pins["decode_truncated"]["out_sha256"]
+    st, rq, out = ctx.stream_decode(comp, 1000)
+    assert [st, rq] == pins["decode_sink_full"]["status"] and len(out) == pins["decode_sink_full"]["size"]
+    assert hashlib.sha256(out).hexdigest() == pins["decode_sink_full"]["out_sha256"]
+
+
+def test_full_size_properties(ctx, oracle):
+    """BASELINE config 2 at full size (1 GiB uniform, 64 KiB blocks): round trip, the size table, and a
+    sample of blocks byte-for-byte against the oracle (the whole GiB would take the CPU a minute)."""
+    from cpprcoder_amd import rcx
+    n, block = 1 << 30, 65536
+    nblocks = n // block
+    g = torch.Generator(device="cuda")
+    g.manual_seed(12345)
+    src = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda", generator=g)
+    dst = torch.empty(rcx.encode_bound(n, block), dtype=torch.uint8, device="cuda")
+    offs = torch.zeros(nblocks + 1, dtype=torch.int64, device="cuda")
+    ctx.encode_blocks_device(src, block, dst, offs)
+    ctx.sync_status()
+    offsets = offs.cpu().numpy()
+    sizes = np.diff(offsets)
+    total = int(offsets[-1])
+    assert sizes.min() >= block and sizes.max() <= block + 200          # uniform bytes do not compress
+    assert abs(total / n - 1.00181) < 2e-4                                # SURVEY section 6.2 ratio @64 KiB
+    out = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ctx.decode_blocks_device(dst, total, offs, n, block, out)
+    ctx.sync_status()
+    assert torch.equal(out, src)
+    # every header says 65536 and every stream ends where the next begins
+    heads = dst[offs[:-1].unsqueeze(1) + torch.arange(4, device="cuda").unsqueeze(0)].cpu().numpy().astype(np.uint32)
+    assert np.all(heads[:, 0] + (heads[:, 1] << 8) + (heads[:, 2] << 16) + (heads[:, 3] << 24) == block)
+    rs = np.random.RandomState(1)
+    picks = sorted(set([0, 1, 63, 64, nblocks - 1] + [int(x) for x in rs.randint(0, nblocks, 123)]))
+    for b in picks:
+        blk = src[b * block:(b + 1) * block].cpu().numpy()
+        (st, _), ref, size = oracle.adaptive_encode(blk)
+        got = dst[int(offsets[b]): int(offsets[b + 1])].cpu().numpy().tobytes()
+        assert st == 0 and got == ref, f"block {b}"
