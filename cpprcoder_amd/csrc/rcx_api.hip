@@ -361,10 +361,6 @@ int rcx_decode_blocks(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
 // ---------------------------------------------------------------------------
 // Single streams with the reference's sink semantics (one block, lane 0 of one wave).
 // ---------------------------------------------------------------------------
-namespace
-{
-u64 sink_round16(u64 cap) { return cap == 0 ? 16 : (cap + 15) & ~(u64)15; } // cpprcoder.h:975
-}
 
 int rcx_stream_encode(rcx_ctx* c, int coder, const uint8_t* src, uint32_t n,
                       uint8_t* dst, uint64_t sink_capacity, uint64_t* dst_size, uint32_t* request_size)
@@ -388,7 +384,7 @@ int rcx_stream_encode(rcx_ctx* c, int coder, const uint8_t* src, uint32_t n,
     if (r != RCX_OK) return r;
     u32 size = 0;
     HIP_TRY(hipMemcpy(&size, c->sizes, sizeof(u32), hipMemcpyDeviceToHost));
-    const u64 cap16 = sink_round16(sink_capacity);
+    const u64 cap16 = sink_capacity < 4 ? 4 : sink_capacity; // the header went through the growing write()
     if ((u64)size - 4 <= cap16) { // every writeByte fits; the final write(4) grows the sink (cpprcoder.h:1031-1045)
         HIP_TRY(hipMemcpy(dst, c->slots, size, hipMemcpyDeviceToHost));
         *dst_size = size;
@@ -422,10 +418,14 @@ int rcx_stream_decode(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
         return RCX_PENDING;
     }
     const u32 declared = (u32)comp[0] | ((u32)comp[1] << 8) | ((u32)comp[2] << 16) | ((u32)comp[3] << 24);
-    const u64 cap16 = sink_round16(sink_capacity);
+    const u64 cap16 = sink_capacity;
     const u64 want = declared ? declared : 1; // cpprcoder.h:912: the size test comes after the first writeByte
     const u64 count = want < cap16 ? want : cap16;
     if (count > RCX_MAX_BLOCK) return RCX_E_ARG;
+    if (count == 0) { // a sink that accepts nothing: the first writeByte fails (cpprcoder.h:909-911)
+        if (request_size) *request_size = declared;
+        return RCX_PENDING;
+    }
     const u32 block = count < RCX_MIN_BLOCK ? RCX_MIN_BLOCK : (u32)count;
     int r = ensure_divtab(c, block);
     if (r != RCX_OK) return r;

@@ -1,0 +1,350 @@
+/*
+ * cpprcoder.h (MI355X facade) -- the reference's class API on top of the rcx C ABI.
+ *
+ * A caller written against taqu/cpprcoder's cpprcoder.h (namespace cpprcoder,
+ * MemoryStream, AdaptiveRangeEncoder<T>, AdaptiveRangeDecoder<T>, Status, Result) can
+ * include this header instead and link librcx.so: the names, argument meaning, return
+ * values and the bytes that reach the sink are the reference's
+ *     Status / Result                      cpprcoder.h:112-123
+ *     IStream<T> / MemoryStream            cpprcoder.h:130-247, 964-1077
+ *     AdaptiveRangeEncoder<T>              cpprcoder.h:626-802
+ *     AdaptiveRangeDecoder<T>              cpprcoder.h:809-940
+ * but the coding itself runs on the GPU (rcx_stream_encode / rcx_stream_decode).
+ *
+ * What differs, by design:
+ *   - The GPU codes whole streams.  encode() collects its pieces until the declared
+ *     size has been seen (returning {Status_Pending, remaining} like the reference)
+ *     and only then emits bytes into the sink; the sink's final contents, the return
+ *     values, and the behaviour of a sink that fills up are the reference's.
+ *   - decode() re-runs over everything it has been fed so far when it is called again
+ *     after Status_Pending.
+ *   - One stream is one GPU lane: this facade is for drop-in compatibility.  Throughput
+ *     comes from coding many blocks at once through rcx_encode_blocks_device (rcx.h),
+ *     see BlockCoder below.
+ *   - Streams longer than RCX_MAX_BLOCK (1 MiB) return Status_Error.
+ */
+#ifndef INC_CPPRCODER_AMD_FACADE_H_
+#define INC_CPPRCODER_AMD_FACADE_H_
+
+#include <cassert>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../rcx.h"
+
+#ifndef CPPRCODER_ASSERT
+#    define CPPRCODER_ASSERT(exp) assert(exp)
+#endif
+
+namespace cpprcoder
+{
+typedef int8_t s8;
+typedef int16_t s16;
+typedef int32_t s32;
+typedef int64_t s64;
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+enum Status
+{
+    Status_Success = RCX_OK,
+    Status_Pending = RCX_PENDING,
+    Status_Error = RCX_ERROR,
+};
+
+struct Result
+{
+    Status status_;
+    u32 requestSize_;
+};
+
+// One rcx context per thread, created on first use on device RCX_DEVICE (default 0).
+inline rcx_ctx* facade_context()
+{
+    static thread_local rcx_ctx* ctx = nullptr;
+    if (!ctx) {
+        const char* dev = getenv("RCX_DEVICE");
+        if (rcx_ctx_create(dev ? atoi(dev) : 0, &ctx) != RCX_OK) ctx = nullptr; // no CPU fallback: callers see Status_Error
+    }
+    return ctx;
+}
+
+//--- IStream (cpprcoder.h:130-166)
+template<class T>
+class IStream
+{
+public:
+    s32 read(s32 size, u8* bytes) { return static_cast<T*>(this)->read(size, bytes); }
+    bool readByte(u8& byte) { return static_cast<T*>(this)->readByte(byte); }
+    s32 write(s32 size, const u8* bytes) { return static_cast<T*>(this)->write(size, bytes); }
+    bool writeByte(u8 byte) { return static_cast<T*>(this)->writeByte(byte); }
+
+protected:
+    IStream() {}
+    ~IStream() {}
+
+private:
+    IStream(const IStream&) = delete;
+    IStream& operator=(const IStream&) = delete;
+};
+
+//--- MemoryStream (cpprcoder.h:185-247, 964-1077): write() grows, writeByte() never does
+class MemoryStream : public IStream<MemoryStream>
+{
+public:
+    MemoryStream() : capacity_(0), size_(0), buffer_(nullptr) {}
+    explicit MemoryStream(s32 capacity) : capacity_(capacity), size_(0)
+    {
+        capacity_ = (capacity_ <= 0) ? 16 : static_cast<s32>((static_cast<u32>(capacity_) + 15U) & ~15U);
+        buffer_ = static_cast<u8*>(malloc(static_cast<size_t>(capacity_)));
+    }
+    ~MemoryStream() { free(buffer_); }
+
+    s32 capacity() const { return capacity_; }
+    s32 size() const { return size_; }
+    const u8* get() const { return buffer_; }
+    const u8& operator[](s32 index) const { CPPRCODER_ASSERT(0 <= index && index < size_); return buffer_[index]; }
+    u8& operator[](s32 index) { CPPRCODER_ASSERT(0 <= index && index < size_); return buffer_[index]; }
+
+    void reserve(s32 capacity) // discards the contents unless the request is smaller (cpprcoder.h:985-994)
+    {
+        capacity = static_cast<s32>((static_cast<u32>(capacity) + 15U) & ~15U);
+        if (capacity < capacity_) return;
+        free(buffer_);
+        capacity_ = capacity;
+        buffer_ = static_cast<u8*>(malloc(static_cast<size_t>(capacity_)));
+    }
+    void resize(s32 size)
+    {
+        CPPRCODER_ASSERT(0 <= size);
+        if (capacity_ < size) reserve(size);
+        size_ = size;
+    }
+    s32 read(s32 size, u8* bytes)
+    {
+        s32 end = size_ + size;
+        if (capacity_ < end) return -1;
+        memcpy(bytes, buffer_ + size_, static_cast<size_t>(size));
+        size_ = end;
+        return size;
+    }
+    bool readByte(u8& byte)
+    {
+        if (capacity_ < size_ + 1) return false;
+        byte = buffer_[size_++];
+        return true;
+    }
+    s32 write(s32 size, const u8* bytes)
+    {
+        s32 end = size_ + size;
+        if (capacity_ < end && !expand(end)) return -1;
+        memcpy(buffer_ + size_, bytes, static_cast<size_t>(size));
+        size_ = end;
+        return size;
+    }
+    bool writeByte(u8 byte)
+    {
+        if (capacity_ <= size_) return false;
+        buffer_[size_++] = byte;
+        return true;
+    }
+
+private:
+    MemoryStream(const MemoryStream&) = delete;
+    MemoryStream& operator=(const MemoryStream&) = delete;
+
+    bool expand(s32 size) // 0 -> 1024, doubling below 16 KiB, then +16 KiB steps (cpprcoder.h:1056-1077)
+    {
+        s32 cap = capacity_;
+        do {
+            if (cap <= 0) cap = 1024;
+            else if (cap < 4096 * 4) cap <<= 1;
+            else cap += 4096 * 4;
+        } while (cap < size);
+        cap = static_cast<s32>((static_cast<u32>(cap) + 15U) & ~15U);
+        u8* fresh = static_cast<u8*>(malloc(static_cast<size_t>(cap)));
+        if (!fresh) return false;
+        if (0 < capacity_) memcpy(fresh, buffer_, static_cast<size_t>(capacity_));
+        free(buffer_);
+        buffer_ = fresh;
+        capacity_ = cap;
+        return true;
+    }
+
+    s32 capacity_;
+    s32 size_;
+    u8* buffer_;
+};
+
+//--- AdaptiveRangeEncoder (cpprcoder.h:626-802)
+template<class T = MemoryStream>
+class AdaptiveRangeEncoder
+{
+public:
+    AdaptiveRangeEncoder() : stream_(nullptr), umcompressedSize_(0), inSize_(0), dead_(false) {}
+
+    // cpprcoder.h:678-695: the header goes out at once through write()
+    bool initialize(T& stream, u32 umcompressedSize)
+    {
+        stream_ = &stream;
+        umcompressedSize_ = umcompressedSize;
+        inSize_ = 0;
+        dead_ = false;
+        input_.clear();
+        input_.reserve(umcompressedSize);
+        u8 bytes[4] = {static_cast<u8>(umcompressedSize), static_cast<u8>(umcompressedSize >> 8),
+                       static_cast<u8>(umcompressedSize >> 16), static_cast<u8>(umcompressedSize >> 24)};
+        return 0 < stream_->write(4, bytes);
+    }
+
+    // cpprcoder.h:697-720
+    Result encode(s32 size, const u8* bytes)
+    {
+        CPPRCODER_ASSERT((inSize_ + size) <= umcompressedSize_);
+        if (dead_) return {Status_Pending, umcompressedSize_ - inSize_};
+        input_.insert(input_.end(), bytes, bytes + size);
+        inSize_ += static_cast<u32>(size);
+        if (umcompressedSize_ <= inSize_) return flush();
+        return {Status_Pending, umcompressedSize_ - inSize_};
+    }
+
+    // cpprcoder.h:722-742
+    Result encode(u8 byte) { return encode(1, &byte); }
+
+private:
+    AdaptiveRangeEncoder(const AdaptiveRangeEncoder&) = delete;
+    AdaptiveRangeEncoder& operator=(const AdaptiveRangeEncoder&) = delete;
+
+    Result flush()
+    {
+        rcx_ctx* ctx = facade_context();
+        if (!ctx) return {Status_Error, 0};
+        const u32 n = umcompressedSize_;
+        std::vector<u8> out(static_cast<size_t>(rcx_block_bound(n < RCX_MIN_BLOCK ? RCX_MIN_BLOCK : n)) + 64);
+        uint64_t size = 0;
+        uint32_t req = 0;
+        if (rcx_stream_encode(ctx, RCX_CODER_ADAPTIVE, input_.data(), n, out.data(), out.size(), &size, &req) != RCX_OK)
+            return {Status_Error, 0};
+        // Replay the reference's sink calls: payload byte by byte through writeByte (never grows),
+        // the last four bytes through write (may grow) -- cpprcoder.h:744-762, 783-800.
+        const uint64_t payload_end = size - 4;
+        for (uint64_t i = 4; i < payload_end; ++i) {
+            if (!stream_->writeByte(out[i])) {
+                dead_ = true; // the reference's coder is unusable from here on too
+                // Which symbol was being coded when byte i did not fit?  Ask the device to replay the
+                // reference's delayed writer against a sink that accepts exactly i bytes.
+                uint64_t size2 = 0;
+                int st = rcx_stream_encode(ctx, RCX_CODER_ADAPTIVE, input_.data(), n, out.data(), i, &size2, &req);
+                if (st == RCX_PENDING) {
+                    inSize_ = n - req;
+                    return {Status_Pending, req}; // cpprcoder.h:708-711
+                }
+                return {Status_Success, 0}; // only finish() ran into the full sink (cpprcoder.h:716)
+            }
+        }
+        stream_->write(4, out.data() + payload_end); // result ignored, as in the reference
+        return {Status_Success, 0};
+    }
+
+    T* stream_;
+    u32 umcompressedSize_;
+    u32 inSize_;
+    bool dead_;
+    std::vector<u8> input_;
+};
+
+//--- AdaptiveRangeDecoder (cpprcoder.h:809-940)
+template<class T = MemoryStream>
+class AdaptiveRangeDecoder
+{
+public:
+    AdaptiveRangeDecoder() : stream_(nullptr), outSize_(0), done_(false) {}
+
+    bool initialize(T& stream) // cpprcoder.h:859-870
+    {
+        stream_ = &stream;
+        outSize_ = 0;
+        done_ = false;
+        fed_.clear();
+        return true;
+    }
+
+    // cpprcoder.h:872-924
+    Result decode(s32 size, const u8* bytes)
+    {
+        if (fed_.empty() && size < 8) return {Status_Pending, 8}; // State_Init needs 8 bytes in one call
+        fed_.insert(fed_.end(), bytes, bytes + size);
+        rcx_ctx* ctx = facade_context();
+        if (!ctx) return {Status_Error, 0};
+        const u32 declared = static_cast<u32>(fed_[0]) | (static_cast<u32>(fed_[1]) << 8) | (static_cast<u32>(fed_[2]) << 16) |
+                             (static_cast<u32>(fed_[3]) << 24);
+        const uint64_t want = declared ? declared : 1;
+        std::vector<u8> out(static_cast<size_t>(want) + 64);
+        uint64_t produced = 0;
+        uint32_t req = 0;
+        int st = rcx_stream_decode(ctx, RCX_CODER_ADAPTIVE, fed_.data(), fed_.size(), out.data(), want, &produced, &req);
+        if (st != RCX_OK && st != RCX_PENDING) return {Status_Error, 0};
+        for (uint64_t i = outSize_; i < produced; ++i) {
+            if (!stream_->writeByte(out[i])) return {Status_Pending, declared - outSize_}; // cpprcoder.h:909-911
+            ++outSize_;
+        }
+        if (st == RCX_PENDING) return {Status_Pending, declared - outSize_}; // input ran dry (cpprcoder.h:901-903)
+        return {Status_Success, 0};
+    }
+
+private:
+    AdaptiveRangeDecoder(const AdaptiveRangeDecoder&) = delete;
+    AdaptiveRangeDecoder& operator=(const AdaptiveRangeDecoder&) = delete;
+
+    T* stream_;
+    u32 outSize_;
+    bool done_;
+    std::vector<u8> fed_;
+};
+
+//--- BlockCoder: the many-blocks entry point in the facade's vocabulary (new; the reference has
+//    no counterpart).  Host buffers in, host buffers out; see rcx.h for the device-pointer calls.
+class BlockCoder
+{
+public:
+    explicit BlockCoder(u32 blockSize = 65536) : block_(blockSize) {}
+
+    // dst is resized to the compacted streams; offsets gets nblocks+1 entries
+    bool encode(std::vector<u8>& dst, std::vector<u64>& offsets, u64 size, const u8* bytes)
+    {
+        rcx_ctx* ctx = facade_context();
+        if (!ctx) return false;
+        const u64 nblocks = rcx_block_count(size, block_);
+        dst.resize(static_cast<size_t>(rcx_encode_bound(size, block_)));
+        offsets.resize(static_cast<size_t>(nblocks + 1));
+        uint64_t total = 0;
+        if (rcx_encode_blocks(ctx, RCX_CODER_ADAPTIVE, bytes, size, block_, dst.data(), dst.size(), &total, offsets.data()) != RCX_OK)
+            return false;
+        dst.resize(static_cast<size_t>(total));
+        return true;
+    }
+
+    bool decode(std::vector<u8>& dst, const std::vector<u8>& src, const std::vector<u64>& offsets)
+    {
+        rcx_ctx* ctx = facade_context();
+        if (!ctx || offsets.empty()) return false;
+        const u64 nblocks = offsets.size() - 1;
+        dst.resize(static_cast<size_t>(nblocks * block_));
+        uint64_t total = 0;
+        if (rcx_decode_blocks(ctx, RCX_CODER_ADAPTIVE, src.data(), src.size(), offsets.data(), nblocks, block_, dst.data(),
+                              dst.size(), &total) != RCX_OK)
+            return false;
+        dst.resize(static_cast<size_t>(total));
+        return true;
+    }
+
+private:
+    u32 block_;
+};
+
+} // namespace cpprcoder
+#endif // INC_CPPRCODER_AMD_FACADE_H_

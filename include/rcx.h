@@ -120,13 +120,15 @@ int rcx_decode_blocks(rcx_ctx* ctx, int coder, const uint8_t* comp, uint64_t com
 /*
  * Single-stream calls with the reference's exact stream semantics, used by the
  * C++ facade: one stream = one block of any size 0 .. RCX_MAX_BLOCK.
- *   rcx_stream_encode == initialize(sink, n); encode(n, src)  into a sink whose
- *       writeByte capacity is sink_capacity (MemoryStream rounds it up to 16,
- *       cpprcoder.h:975): returns RCX_OK, or RCX_PENDING with *request_size set as
- *       cpprcoder.h:708-711 does when the sink fills (dst then holds the bytes
- *       written so far).
+ *   rcx_stream_encode == initialize(sink, n); encode(n, src)  into a sink that holds
+ *       exactly sink_capacity bytes before writeByte fails (for a MemoryStream that is
+ *       its capacity(), i.e. the constructor argument rounded up to 16, cpprcoder.h:975):
+ *       returns RCX_OK, or RCX_PENDING with *request_size set as cpprcoder.h:708-711
+ *       does when the sink fills (dst then holds the sink_capacity bytes written so far).
+ *       dst must have room for min(sink_capacity, rcx_block_bound(n)) bytes.
  *   rcx_stream_decode == initialize(sink); decode(comp_size, comp): RCX_OK,
- *       RCX_PENDING (+ request_size) for short input or a full sink, including the
+ *       RCX_PENDING (+ request_size) for short input or a full sink (one that accepts
+ *       sink_capacity bytes), including the
  *       reference's quirk that a stream declaring 0 bytes yields one byte (cpprcoder.h:912).
  */
 int rcx_stream_encode(rcx_ctx* ctx, int coder, const uint8_t* src, uint32_t n,
