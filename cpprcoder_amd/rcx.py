@@ -132,7 +132,8 @@ class Context:
     def encode_blocks_device(self, src, block: int, dst, offsets, coder: int = CODER_ADAPTIVE, stream=None) -> None:
         """src: uint8 cuda tensor; dst: uint8 cuda tensor (>= encode_bound); offsets: int64 cuda tensor [nblocks+1]."""
         n = src.numel()
-        assert offsets.numel() >= block_count(n, block) + 1
+        if MIN_BLOCK <= block <= MAX_BLOCK and offsets.numel() < block_count(n, block) + 1:
+            raise ValueError("offsets needs nblocks+1 entries")
         st = lib().rcx_encode_blocks_device(self._h, coder, src.data_ptr(), n, block, dst.data_ptr(), dst.numel(),
                                             offsets.data_ptr(), self._stream_handle(stream))
         _check(st, "rcx_encode_blocks_device")

@@ -1,0 +1,94 @@
+// facade_test.cpp -- drives include/cpprcoder_amd/cpprcoder.h the way the reference harness drives
+// cpprcoder.h (test/main.cpp:321-344) and the way its disabled unit test does (test/main.cpp:1200-1238).
+// Built and run by tests/test_gpu_facade.py on the GPU box; results go to stdout / an output file and
+// are compared with the oracle there.
+//
+//   facade_test enc  <in> <out> <sink_capacity> <piece>   piece: 0 = one call, N = pieces of N bytes, -1 = encode(u8)
+//   facade_test dec  <in> <out> <sink_capacity> <piece>
+//   facade_test blocks <in> <out> <block>                  BlockCoder round trip; out = compacted streams
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+#include <vector>
+
+#include "cpprcoder_amd/cpprcoder.h"
+
+static std::vector<cpprcoder::u8> slurp(const char* path)
+{
+    std::ifstream f(path, std::ios::binary);
+    return std::vector<cpprcoder::u8>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+static void dump(const char* path, const cpprcoder::u8* p, size_t n)
+{
+    std::ofstream f(path, std::ios::binary);
+    f.write(reinterpret_cast<const char*>(p), static_cast<std::streamsize>(n));
+}
+
+int main(int argc, char** argv)
+{
+    using namespace cpprcoder;
+    if (argc < 5) return 2;
+    std::vector<u8> in = slurp(argv[2]);
+    if (!strcmp(argv[1], "enc")) {
+        s32 cap = atoi(argv[4]);
+        int piece = atoi(argv[5]);
+        MemoryStream sink(cap);
+        AdaptiveRangeEncoder<> enc;
+        if (!enc.initialize(sink, static_cast<u32>(in.size()))) return 3;
+        Result r = {Status_Success, 0};
+        if (piece == 0 || in.empty()) {
+            r = enc.encode(static_cast<s32>(in.size()), in.data());
+        } else if (piece < 0) {
+            for (size_t i = 0; i < in.size(); ++i) r = enc.encode(in[i]);
+        } else {
+            for (size_t at = 0; at < in.size(); at += piece) {
+                size_t len = in.size() - at < static_cast<size_t>(piece) ? in.size() - at : piece;
+                r = enc.encode(static_cast<s32>(len), in.data() + at);
+            }
+        }
+        dump(argv[3], sink.get(), static_cast<size_t>(sink.size()));
+        printf("%d %u %d %d\n", static_cast<int>(r.status_), r.requestSize_, sink.size(), sink.capacity());
+        return 0;
+    }
+    if (!strcmp(argv[1], "dec")) {
+        s32 cap = atoi(argv[4]);
+        int piece = atoi(argv[5]);
+        MemoryStream sink(cap);
+        AdaptiveRangeDecoder<> dec;
+        dec.initialize(sink);
+        Result r = {Status_Pending, 0};
+        if (piece <= 0) {
+            r = dec.decode(static_cast<s32>(in.size()), in.data());
+        } else {
+            size_t at = 0;
+            bool first = true;
+            while (at < in.size()) {
+                size_t len = in.size() - at < static_cast<size_t>(piece) ? in.size() - at : piece;
+                if (first && len < 8) len = in.size() - at < 8 ? in.size() - at : 8;
+                first = false;
+                r = dec.decode(static_cast<s32>(len), in.data() + at);
+                at += len;
+                if (r.status_ != Status_Pending) break;
+            }
+        }
+        dump(argv[3], sink.get(), static_cast<size_t>(sink.size()));
+        printf("%d %u %d %d\n", static_cast<int>(r.status_), r.requestSize_, sink.size(), sink.capacity());
+        return 0;
+    }
+    if (!strcmp(argv[1], "blocks")) {
+        u32 block = static_cast<u32>(atoi(argv[4]));
+        BlockCoder coder(block);
+        std::vector<u8> comp, back;
+        std::vector<u64> offsets;
+        if (!coder.encode(comp, offsets, in.size(), in.data())) return 4;
+        if (!coder.decode(back, comp, offsets)) return 5;
+        if (back != in) return 6;
+        dump(argv[3], comp.data(), comp.size());
+        printf("%zu %zu\n", comp.size(), offsets.size());
+        return 0;
+    }
+    return 2;
+}

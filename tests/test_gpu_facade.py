@@ -1,0 +1,76 @@
+"""The C++ facade (include/cpprcoder_amd/cpprcoder.h) compiled with g++ and run on the GPU box:
+a caller written against the reference's class API gets the reference's bytes and return values
+(cpprcoder.h:626-940), with the coding done on the MI355X."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cpprcoder_amd import workloads
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("facade") / "facade_test")
+    lib = os.path.join(ROOT, "cpprcoder_amd")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "facade_test.cpp"),
+                    "-o", out, "-L", lib, "-lrcx", f"-Wl,-rpath,{lib}"], check=True)
+    return out
+
+
+def run(exe, tmp_path, mode, data, *args):
+    src, dst = tmp_path / "in.bin", tmp_path / "out.bin"
+    src.write_bytes(bytes(data))
+    p = subprocess.run([exe, mode, str(src), str(dst)] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.returncode, p.stderr)
+    return [int(x) for x in p.stdout.split()], dst.read_bytes()
+
+
+def test_facade_encode_decode_like_the_reference(exe, tmp_path, oracle):
+    cases = [b"", b"hello world", workloads.zipf(20000, 5).tobytes(), workloads.uniform(65536, 12345).tobytes(),
+             workloads.canterbury_files()["alice29.txt"]]
+    for v in cases:
+        n = len(v)
+        (rst, rrq), rout, rsize = oracle.adaptive_encode(v, sink_capacity=n + n // 32 + 1024)
+        for piece in (0, 777, -1) if n <= 20000 else (0, 4096):
+            (st, rq, size, cap), out = run(exe, tmp_path, "enc", v, n + n // 32 + 1024, piece)
+            assert (st, rq, size) == (rst, rrq, rsize) and out == rout, (n, piece)
+        for piece in (0, 1000):
+            (st, rq, size, cap), back = run(exe, tmp_path, "dec", rout, max(n, 16), piece)
+            assert (st, rq) == (0, 0) and back == (v if v else b"\x00")
+    assert oracle.adaptive_encode(cases[-1])[2] == 87147  # README.md:36
+
+
+def test_facade_full_sink(exe, tmp_path, oracle, golden):
+    u = workloads.uniform(65536, 12345)
+    (st, rq, size, cap), out = run(exe, tmp_path, "enc", u.tobytes(), 65536, 0)   # {Pending, 112}
+    (rst, rrq), rout, rsize = oracle.adaptive_encode(u, sink_capacity=65536)
+    assert (st, rq, size) == (rst, rrq, rsize) == (1, 112, 65536) and out == rout
+    rs = np.random.RandomState(3)
+    for _ in range(6):
+        n = int(rs.randint(100, 3000))
+        v = workloads.zipf(n, int(rs.randint(1 << 20))).tobytes()
+        full = oracle.adaptive_encode(v)[2]
+        cap = int(rs.randint(16, full))
+        (rst, rrq), rout, rsize = oracle.adaptive_encode(v, sink_capacity=cap)
+        (st, rq, size, _), out = run(exe, tmp_path, "enc", v, cap, 0)
+        assert (st, rq, size) == (rst, rrq, rsize) and out[: len(rout)] == rout
+    comp = oracle.adaptive_encode(u[:3000])[1]
+    (st, rq, size, _), out = run(exe, tmp_path, "dec", comp[:1500], 3000, 0)      # input runs dry
+    pin = golden["kat"]["pins"]["decode_truncated"]
+    assert [st, rq] == pin["status"] and size == pin["size"]
+    (st, rq, size, _), out = run(exe, tmp_path, "dec", comp, 1000, 0)             # sink fills
+    pin = golden["kat"]["pins"]["decode_sink_full"]
+    assert [st, rq] == pin["status"] and size == pin["size"]
+
+
+def test_facade_block_coder(exe, tmp_path, oracle):
+    data = workloads.canterbury_tiled(700_001)
+    (total, noff), comp = run(exe, tmp_path, "blocks", data.tobytes(), 65536)
+    slots, sizes = oracle.encode_blocks(data, 65536, threads=4)
+    payload, offsets = oracle.compact(slots, sizes)
+    assert total == len(payload) and noff == len(offsets) and comp == payload.tobytes()
