@@ -33,6 +33,8 @@ struct EventPair {
 
 struct rcx_ctx {
     int device = 0;
+    int lanes_per_block = 1; // decode: 1 = one lane per block, 8 = octet kernel (RCX_LANES_PER_BLOCK)
+    int enc_variant = 2;     // encode: 0 = one lane per block, 1 = octet, 2 = model/coder wave split (RCX_ENC_VARIANT)
     // scratch
     u8* slots = nullptr;
     u64 slots_bytes = 0;
@@ -177,6 +179,8 @@ int rcx_ctx_create(int device, rcx_ctx** out)
     rcx_ctx* c = new (std::nothrow) rcx_ctx();
     if (!c) return RCX_E_NOMEM;
     c->device = device;
+    if (const char* v = getenv("RCX_LANES_PER_BLOCK")) c->lanes_per_block = atoi(v) == 8 ? 8 : 1;
+    if (const char* v = getenv("RCX_ENC_VARIANT")) c->enc_variant = atoi(v) >= 0 && atoi(v) <= 2 ? atoi(v) : 2;
     if (hipMalloc(reinterpret_cast<void**>(&c->status), 4 * sizeof(u32)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&c->status_host), 4 * sizeof(u32), hipHostMallocDefault) != hipSuccess) {
         rcx_ctx_destroy(c);
@@ -247,15 +251,25 @@ int rcx_encode_blocks_device(rcx_ctx* c, int coder, const void* d_src, uint64_t 
     HIP_TRY(hipSetDevice(c->device));
     const u64 nblocks = rcx_block_count(n, block);
     if (nblocks == 0) return hipMemsetAsync(d_offsets, 0, sizeof(u64), s) == hipSuccess ? RCX_OK : RCX_E_HIP;
-    if (nblocks > 0x7FFFFFFFull) return RCX_E_ARG;
+    if (nblocks > 0x7FFFFFFFull) return RCX_E_ARG; // grid.x limit with 8 blocks per workgroup to spare
     int r = reserve(c, n, block);
     if (r != RCX_OK) return r;
     const u64 slot = rcx_block_bound(block);
     {
         Timed t(c, s, RCX_T_ENCODE);
-        const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
-        hipLaunchKernelGGL(rcx_enc_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block, nblocks,
-                           c->slots, slot, c->sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr));
+        if (c->enc_variant == 2) {
+            const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
+            hipLaunchKernelGGL(rcx_enc_mc_k, dim3(grid), dim3(RCX_MC_THREADS), 0, s, static_cast<const u8*>(d_src), n, block, nblocks,
+                               c->slots, slot, c->sizes, c->divtab, c->status);
+        } else if (c->enc_variant == 1) {
+            const u32 grid = (u32)((nblocks + RCX_OCT_BLOCKS - 1) / RCX_OCT_BLOCKS);
+            hipLaunchKernelGGL(rcx_enc_oct_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block, nblocks,
+                               c->slots, slot, c->sizes, c->divtab, c->status);
+        } else {
+            const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
+            hipLaunchKernelGGL(rcx_enc_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block,
+                               nblocks, c->slots, slot, c->sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr));
+        }
     }
     {
         Timed t(c, s, RCX_T_SCAN);
@@ -285,9 +299,15 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
     if (r != RCX_OK) return r;
     {
         Timed t(c, s, RCX_T_DECODE);
-        const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
-        hipLaunchKernelGGL(rcx_dec_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
-                           block, n, static_cast<u8*>(d_dst), c->divtab, c->status, static_cast<u32*>(nullptr));
+        if (c->lanes_per_block == 8) {
+            const u32 grid = (u32)((nblocks + RCX_OCT_BLOCKS - 1) / RCX_OCT_BLOCKS);
+            hipLaunchKernelGGL(rcx_dec_oct_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
+                               block, n, static_cast<u8*>(d_dst), c->divtab, c->status);
+        } else {
+            const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
+            hipLaunchKernelGGL(rcx_dec_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets,
+                               nblocks, block, n, static_cast<u8*>(d_dst), c->divtab, c->status, static_cast<u32*>(nullptr));
+        }
     }
     return hipGetLastError() == hipSuccess ? RCX_OK : RCX_E_HIP;
 }
@@ -458,6 +478,19 @@ int rcx_stream_decode(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
     *dst_size = produced;
     return result;
 }
+
+#if defined(RCX_STAMP_DEC)
+int rcx_debug_dec_stamps(unsigned long long* out8)
+{
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(rcx_dec_stamp_out), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+#if defined(RCX_STAMP)
+int rcx_debug_stamps(unsigned long long* out16)
+{
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(rcx_stamp_out), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int rcx_ctx_set_timing(rcx_ctx* c, int enabled)
 {

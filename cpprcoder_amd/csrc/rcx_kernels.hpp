@@ -69,8 +69,9 @@ __global__ __launch_bounds__(64) void rcx_enc_adaptive_k(const u8* __restrict__ 
     DivEntry* stage = reinterpret_cast<DivEntry*>(lds + RCX_GROUPS * RCX_LANES);
 
     EncLane enc;
-    if (live) enc.begin(slots + blk * slot, (u32)slot, len);
-    else enc.idle();
+    u8* wave_slots = slots + (u64)blockIdx.x * RCX_LANES * slot; // wave-uniform; a lane's slot is a 32-bit offset from it
+    if (live) enc.begin(wave_slots, lane * (u32)slot, (u32)slot, len);
+    else enc.idle(wave_slots);
     if (STREAM) enc.trk_cap = sink_bytes;
 
     const u32 maxlen = rcx_wave_max(len);
@@ -192,6 +193,9 @@ __global__ __launch_bounds__(256) void rcx_scatter_k(const u8* __restrict__ slot
 // ===========================================================================
 // Decode
 // ===========================================================================
+#if defined(RCX_STAMP_DEC)
+static __device__ unsigned long long rcx_dec_stamp_out[8];
+#endif
 // STREAM = the single-stream entry point: one block whose symbol count n the host took from
 // the header (max(declared,1) clipped to the sink); track[0] = first symbol whose normalize
 // ran out of input, or 0xFFFFFFFF.
@@ -212,6 +216,10 @@ __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ 
     DivEntry* stage = reinterpret_cast<DivEntry*>(lds + RCX_GROUPS * RCX_LANES);
 
     DecLane dec;
+#if defined(RCX_STAMP_DEC)
+    for (int i_ = 0; i_ < 8; ++i_) dec.stamp_sum[i_] = 0;
+    dec.stamp_last = __builtin_amdgcn_s_memtime();
+#endif
     u64 stream_len = 0;
     if (live) {
         const u64 s0 = offsets[blk], s1 = offsets[blk + 1];
@@ -229,15 +237,7 @@ __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ 
             }
         }
     }
-    if (!live) {
-        dec.low = 0;
-        dec.range = 0x01000000u;
-        dec.win = 0;
-        dec.navail8 = 64;
-        dec.next = comp;
-        dec.end = comp;
-        dec.taken = 0;
-    }
+    if (!live) dec.idle(comp);
 
     const u32 maxlen = rcx_wave_max(len);
     const bool full = !STREAM && __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
@@ -252,9 +252,12 @@ __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ 
             for (u32 j0 = 0; j0 < jend; j0 += 16) {
                 const u32 i = i0 + j0;
                 u32 word[4] = {0, 0, 0, 0};
+                DivEntry k_next = stage[j0]; // divisor of the next symbol: fetched one symbol early
 #pragma unroll
                 for (u32 j = 0; j < 16; ++j) {
-                    const u32 c = dec.step(tree, stage[j0 + j], i + j + 1 == maxlen);
+                    const DivEntry k = k_next;
+                    if (j + 1 < 16) k_next = stage[j0 + j + 1];
+                    const u32 c = dec.step(tree, k);
                     word[j >> 2] |= c << (8 * (j & 3));
                 }
                 U4 o;
@@ -273,14 +276,20 @@ __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ 
             for (u32 j = 0; j < jend; ++j) {
                 const u32 i = i0 + j;
                 const DivEntry k = stage[j];
-                if (i < len) out[i] = (u8)dec.template step<STREAM>(tree, k, i + 1 == len, i, stream_len);
+                if (i < len) out[i] = (u8)dec.template step<STREAM>(tree, k, i, stream_len);
             }
         }
     }
+#if defined(RCX_STAMP_DEC)
+    if (blockIdx.x == 7 && lane == 0)
+        for (int i_ = 0; i_ < 8; ++i_) rcx_dec_stamp_out[i_] = dec.stamp_sum[i_];
+#endif
     // the reference returns Status_Pending when normalize runs out of input (cpprcoder.h:901-903)
     if (STREAM) {
         if (live) track[0] = dec.short_at;
-    } else if (live && dec.taken > stream_len) {
+    } else if (live && dec.taken() > stream_len) {
         rcx_flag(status, RCX_ST_CORRUPT, blk);
     }
 }
+
+#include "rcx_oct.hpp"

@@ -84,16 +84,23 @@ RCX_DEV u32 rcx_mul24(u32 a, u32 b) { return __umul24(a, b); }
 RCX_DEV u32 rcx_perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 RCX_DEV u32 rcx_bswap(u32 x) { return __builtin_bswap32(x); }
 RCX_DEV void rcx_lds_inc(u32* p) { (void)__hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+RCX_DEV void rcx_lds_add(u32* p, u32 v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 RCX_DEV float rcx_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #endif
 
+#if defined(RCX_ABLATE_DIV) /* timing experiments only */
+RCX_DEV u32 rcx_div(u32 n, const DivEntry& k) { return (n >> 9) + (k.mul & 1) + (k.add & 1) + (k.shift & 1); }
+#else
 RCX_DEV u32 rcx_div(u32 n, const DivEntry& k) { return (u32)(((u64)n * k.mul + k.add) >> 32) >> k.shift; }
+#endif
 
 // The tree of one lane.  `base` already includes the lane offset.
 struct Tree {
     U4* base;
     RCX_DEV U4 group(u32 g) const { return base[g * RCX_LANES]; }
     RCX_DEV void bump(u32 g, u32 p) const { rcx_lds_inc(reinterpret_cast<u32*>(&base[g * RCX_LANES]) + p); }
+    // same effect as bump() when the caller already holds the element's current value
+    RCX_DEV void put(u32 g, u32 p, u32 value) const { (reinterpret_cast<u32*>(&base[g * RCX_LANES]))[p] = value; }
     // cpprcoder.h:1094-1132: every count 1.
     RCX_DEV void reset() const
     {
@@ -139,17 +146,21 @@ RCX_DEV u32 rcx_sel4(const U4& g, u32 p)
 // once and a carry is added into the bytes already produced, which yields the
 // same stream as the reference's held-byte + pending-0xFF counter
 // (cpprcoder.h:767-800).  The newest 1..7 bytes live in `acc` (big-endian
-// number, newest byte lowest) so that a carry is one integer add; only when it
-// runs out of the register does it walk back through memory (rare).
+// number, newest byte lowest) so that a carry is one 64-bit add.  A carry that
+// runs through every held byte leaves a bit just above them; it is noticed when
+// the bytes are flushed and only then walks back through memory (about 9e-5 per
+// symbol on random data).
 // ---------------------------------------------------------------------------
 struct EncLane {
     u32 low, range;
-    u32 acc_lo, acc_hi; // pending output bytes, acc_hi is only non-zero between append and flush
+    u64 acc;            // pending output bytes in the low nacc8 bits (+ possibly a carry bit above them)
     u32 nacc8;          // 8 * number of bytes in acc; 8..32 between steps
     u32 pos;            // payload bytes already stored
-    u32 cap;            // payload capacity of the slot (bytes)
+    u32 cap;            // payload capacity of the slot (bytes, multiple of 4, >= 12)
     u32 overflow;       // slot too small: output is dropped from here on
-    u8* payload;        // slot + 4
+    u8* base;           // wave-uniform base of the slots this wave writes
+    u32 off;            // this lane's payload offset from base (slot offset + 4)
+    bool leader;        // several lanes may run one block's coder in lock-step; only the leader stores
     // TRACK only: where the reference's delayed writer (held byte + pending run,
     // cpprcoder.h:767-800) stands, to find the symbol at which a bounded sink fills.
     u32 trk_written;    // payload bytes the reference has passed to writeByte so far
@@ -157,65 +168,72 @@ struct EncLane {
     u32 trk_cap;        // writeByte calls that succeed (sink capacity - 4 header bytes)
     u32 trk_fail_at;    // first symbol whose normalize hits the full sink, or 0xFFFFFFFF
 
-    RCX_DEV void begin(u8* slot, u32 slot_bytes, u32 declared)
+    RCX_DEV u8* payload() const { return base + off; }
+
+    RCX_DEV void reset_state()
     {
-        // cpprcoder.h:678-695: u32 LE size, then the coder state; the reference's first
-        // emitted byte is its initial buffer_ = 0, here already sitting in acc.
+        low = 0;
+        range = 0xFFFFFF00u;
+        acc = 0; // the reference's first emitted byte is its initial buffer_ = 0: already "held" here
+        nacc8 = 8;
+        pos = 0;
+        overflow = 0;
+        leader = true;
+        trk_written = 0;
+        trk_pending = 0;
+        trk_cap = 0xFFFFFFFFu;
+        trk_fail_at = 0xFFFFFFFFu;
+    }
+
+    // cpprcoder.h:678-695: u32 LE size, then the coder state.  The slot is wave_base + slot_off.
+    RCX_DEV void begin(u8* wave_base, u32 slot_off, u32 slot_bytes, u32 declared)
+    {
+        u8* slot = wave_base + slot_off;
         slot[0] = (u8)declared;
         slot[1] = (u8)(declared >> 8);
         slot[2] = (u8)(declared >> 16);
         slot[3] = (u8)(declared >> 24);
-        payload = slot + 4;
-        cap = slot_bytes - 4;
-        low = 0;
-        range = 0xFFFFFF00u;
-        acc_lo = 0;
-        acc_hi = 0;
-        nacc8 = 8;
-        pos = 0;
-        overflow = 0;
-        trk_written = 0;
-        trk_pending = 0;
-        trk_cap = 0xFFFFFFFFu;
-        trk_fail_at = 0xFFFFFFFFu;
+        base = wave_base;
+        off = slot_off + 4;
+        cap = (slot_bytes - 4) & ~3u;
+        reset_state();
     }
 
     // a lane without a block: keeps the arithmetic well-defined, never stores
-    RCX_DEV void idle()
+    RCX_DEV void idle(u8* wave_base)
     {
-        payload = nullptr;
+        base = wave_base;
+        off = 0;
         cap = 0;
-        low = 0;
-        range = 0xFFFFFF00u;
-        acc_lo = 0;
-        acc_hi = 0;
-        nacc8 = 8;
-        pos = 0;
-        overflow = 0;
-        trk_written = 0;
-        trk_pending = 0;
-        trk_cap = 0xFFFFFFFFu;
-        trk_fail_at = 0xFFFFFFFFu;
+        reset_state();
+        leader = false;
     }
 
-    // carry ran through every byte held in acc: continue in memory (cpprcoder.h:767-781)
-    RCX_DEV void carry_into_memory()
+    // `extra` carries ran through every byte held in acc: continue in memory (cpprcoder.h:767-781)
+    RCX_DEV void carry_into_memory(u32 extra)
     {
-        u32 p = pos;
+        u32 p = leader ? (pos < cap ? pos : 0) : 0;
+        u8* out = payload();
         RCX_SIM_COUNT(0, 1);
-        while (p > 0) {
+        while (p > 0 && extra) {
             --p;
             RCX_SIM_COUNT(1, 1);
-            u8 v = (u8)(payload[p] + 1);
-            payload[p] = v;
-            if (v != 0) break;
+            u32 v = (u32)out[p] + extra;
+            out[p] = (u8)v;
+            extra = v >> 8;
         }
     }
 
     RCX_DEV void store4(u32 word_le)
     {
-        if (pos + 4 <= cap) *reinterpret_cast<u32*>(payload + pos) = word_le;
-        else overflow = 1;
+        const bool ok = pos + 4 <= cap;
+        const u32 where = ok ? pos : cap - 4; // a too-small slot keeps overwriting its last word
+        overflow |= ok ? 0u : 1u;
+#if !defined(RCX_ABLATE_STORE) /* timing experiments only: never defined in a shipped build */
+        if (leader) *reinterpret_cast<u32*>(base + (off + where)) = word_le;
+#else
+        asm volatile("" ::"v"(word_le), "v"(where));
+#endif
         pos += 4;
     }
 
@@ -242,6 +260,51 @@ struct EncLane {
     // TRUE when finish() (cpprcoder.h:744-755) would run into the full sink
     RCX_DEV bool track_flush_fails() const { return trk_written + 1 + trk_pending > trk_cap; }
 
+    // One symbol with the model's answer already in hand: cum = sum of the counts below the
+    // symbol, f = its count (cpprcoder.h:703-711).
+    template <bool TRACK = false>
+    RCX_DEV void code(u32 cum, u32 f, const DivEntry& k, u32 index = 0)
+    {
+        const u32 t = rcx_div(range, k);             // cpprcoder.h:703
+        const u32 moved = low + rcx_mul24(cum, t);   // :706  (cum*t <= range < 2^32, both factors < 2^24)
+        const u32 carry = moved < low ? 1u : 0u;
+        range = rcx_mul24(f, t);                     // :707
+        acc += carry;                                // :767-781, resolved lazily (see flush)
+
+        // :783-800 renormalise: k8/8 bytes leave through the top of low
+        const u32 k8 = rcx_clz(range) & 0x18u;
+        if (TRACK) track(index, carry, moved, k8);
+#if defined(RCX_ABLATE_EMIT) /* timing experiments only */
+        const u64 shifted = (u64)moved << k8;
+        low = (u32)shifted;
+        acc ^= moved;
+#else
+        const u64 shifted = (u64)moved << k8;
+        low = (u32)shifted;
+        acc = (acc << k8) | (shifted >> 32);
+#endif
+        range <<= k8;
+        nacc8 += k8;
+#if !defined(RCX_ABLATE_FLUSH)
+        if (nacc8 >= 40) flush();
+#else
+        nacc8 &= 31u;
+#endif
+    }
+
+    // 5..7 bytes held: store the 4 oldest, keep 1..3
+    RCX_DEV void flush()
+    {
+        const u32 keep8 = nacc8 - 32;
+        const u64 top = acc >> keep8; // 4 oldest bytes, and above them any carry that ran off the held bytes
+        const u32 extra = (u32)(top >> 32);
+        if (extra) carry_into_memory(extra);
+        store4(rcx_bswap((u32)top));
+        acc &= ((u64)1 << keep8) - 1;
+        nacc8 = keep8;
+    }
+
+    // One lane per block: model query, code, model update.
     template <bool TRACK = false, class TreeT>
     RCX_DEV void step(const TreeT& tree, u32 c, const DivEntry& k, u32 index = 0)
     {
@@ -251,55 +314,27 @@ struct EncLane {
         const U4 g0 = tree.group(RCX_G_L0 + (c >> 2));
         const u32 cum = rcx_pre4(g3, c >> 6) + rcx_pre4(g2, (c >> 4) & 3) + rcx_pre4(g1, (c >> 2) & 3) + rcx_pre4(g0, c & 3);
         const u32 f = rcx_sel4(g0, c & 3);
-
-        const u32 t = rcx_div(range, k);          // cpprcoder.h:703
-        u32 moved = low + rcx_mul24(cum, t);      // :706  (cum*t <= range < 2^32, both factors < 2^24)
-        const u32 carry = moved < low ? 1u : 0u;
-        range = rcx_mul24(f, t);                  // :707
-
-        // :767-781 carry into the bytes produced so far
-        acc_lo += carry;
-        const u32 wrapped = 2u << (nacc8 - 1);    // 2^(nacc8) truncated to 32 bits (0 when 4 bytes are held)
-        if (carry && acc_lo == wrapped) {
-            acc_lo = 0;
-            carry_into_memory();
-        }
-
-        // :783-800 renormalise: k8/8 bytes leave through the top of low
-        const u32 k8 = rcx_clz(range) & 0x18u;
-        if (TRACK) track(index, carry, moved, k8);
-        const u64 pair = (((u64)acc_lo << 32) | moved) << k8; // {acc_lo, low} shifted together
-        acc_hi = (u32)((u64)acc_lo >> (32 - k8));              // k8 == 0 -> acc_lo >> 32 == 0
-        acc_lo = (u32)(pair >> 32);
-        low = (u32)pair;
-        range <<= k8;
-        nacc8 += k8;
-
-        if (nacc8 >= 40) { // 5..7 bytes held: store the 4 oldest, keep 1..3
-            const u32 keep8 = nacc8 - 32;
-            const u32 r = keep8 >> 3;
-            store4(rcx_perm(acc_hi, acc_lo, 0x00010203u + rcx_perm(0u, r, 0u) /* r in every byte */));
-            acc_lo &= (1u << keep8) - 1u;
-            acc_hi = 0;
-            nacc8 = keep8;
-        }
+        code<TRACK>(cum, f, k, index);
         tree.update(c); // :712
     }
 
     // cpprcoder.h:744-762: the held bytes, then low big-endian.  Returns the stream size.
     RCX_DEV u32 finish()
     {
-        u32 n = nacc8 >> 3;
+        const u32 extra = (u32)(acc >> nacc8);
+        if (extra) carry_into_memory(extra);
+        const u32 n = nacc8 >> 3;
+        u8* out = payload();
         for (u32 i = 0; i < n; ++i) {
-            u8 b = (u8)(acc_lo >> (8 * (n - 1 - i)));
-            if (pos < cap) payload[pos] = b;
-            else overflow = 1;
+            u8 b = (u8)(acc >> (8 * (n - 1 - i)));
+            if (pos >= cap) overflow = 1;
+            else if (leader) out[pos] = b;
             ++pos;
         }
         for (u32 i = 0; i < 4; ++i) {
             u8 b = (u8)(low >> (24 - 8 * i));
-            if (pos < cap) payload[pos] = b;
-            else overflow = 1;
+            if (pos >= cap) overflow = 1;
+            else if (leader) out[pos] = b;
             ++pos;
         }
         return pos + 4;
@@ -308,17 +343,43 @@ struct EncLane {
 
 // ---------------------------------------------------------------------------
 // Decoder lane.
+//
+// find() (cpprcoder.h:1220-1242) runs in the scaled domain: with t = range/total the
+// reference's "cum(c) <= low/t < cum(c+1)" (cpprcoder.h:905) is "cum(c)*t <= low <
+// cum(c+1)*t"; every product is <= total*t <= range < 2^32, so the second divide is not
+// needed and low - cum(c)*t (cpprcoder.h:906) is what is left when the descent ends.
 // ---------------------------------------------------------------------------
 struct DecLane {
     u32 low, range;
     u64 win;            // upcoming stream bytes, left-aligned (next byte on top)
     u32 navail8;        // 8 * bytes in win
-    const u8* next;     // next aligned dword to load
+    u32 ahead;          // the dword after the window, loaded one refill early; kept RAW (memory order) so that
+                        // nothing touches it -- and waits for the load -- before the next refill
+    const u8* next;     // the aligned dword after `ahead`
+    const u8* body;     // first stream byte after the 8 header bytes
     const u8* end;      // one past the block's stream
-    u64 taken;          // stream bytes consumed by normalize (for the truncation check)
     u32 short_at;       // TRACK only: first symbol whose normalize ran past the input, or 0xFFFFFFFF
+#if defined(RCX_STAMP_DEC) /* diagnostic build only */
+    unsigned long long stamp_sum[8];
+#define RCX_DSTAMP(i)                                            \
+    {                                                            \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        unsigned long long now_;                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        stamp_sum[i] += now_ - stamp_last;                       \
+        stamp_last = now_;                                       \
+    }
+    unsigned long long stamp_last;
+#else
+#define RCX_DSTAMP(i)
+#endif
 
-    RCX_DEV u32 load_be(const u8* p) const { return rcx_bswap(*reinterpret_cast<const u32*>(p)); }
+#if defined(RCX_ABLATE_DLOAD) /* timing experiments only */
+    RCX_DEV u32 load_raw(const u8* p) const { return (u32)(uintptr_t)p * 2654435761u; }
+#else
+    RCX_DEV u32 load_raw(const u8* p) const { return p < end ? *reinterpret_cast<const u32*>(p) : 0u; }
+#endif
 
     // cpprcoder.h:877-896 + :859-870.  `s` points at the block's stream (any alignment),
     // which must be at least 8 bytes long.  Returns the declared size.
@@ -328,91 +389,127 @@ struct DecLane {
         low = ((u32)s[4] << 24) | ((u32)s[5] << 16) | ((u32)s[6] << 8) | (u32)s[7];
         range = 0x00FFFFFFu;
         end = stream_end;
-        const u8* body = s + 8;
-        u32 skew = (u32)((uintptr_t)body & 3);
+        body = s + 8;
+        const u32 skew = (u32)((uintptr_t)body & 3);
         next = body - skew;
-        win = 0;
-        navail8 = 0;
-        taken = 8;
-        short_at = 0xFFFFFFFFu;
-        if (next < end) {
-            win = (u64)(load_be(next) << (8 * skew)) << 32;
-            navail8 = 32 - 8 * skew;
-        } else {
-            navail8 = 32; // past the end: zeros
-        }
+        win = (u64)(rcx_bswap(load_raw(next)) << (8 * skew)) << 32; // past the end: zeros
+        navail8 = 32 - 8 * skew;
         next += 4;
+        ahead = load_raw(next);
+        next += 4;
+        short_at = 0xFFFFFFFFu;
         return declared;
     }
 
-    RCX_DEV void refill()
+    // a lane without a block
+    RCX_DEV void idle(const u8* anywhere)
     {
-        u32 d = 0;
-        if (next < end) d = load_be(next);
-        next += 4;
-        win |= (u64)d << (32 - navail8);
-        navail8 += 32;
+        low = 0;
+        range = 0x01000000u;
+        win = 0;
+        navail8 = 64;
+        ahead = 0;
+        next = body = end = anywhere;
+        short_at = 0xFFFFFFFFu;
     }
 
-    // Decodes one symbol.  `total` = 256 + symbols decoded so far.
-    template <bool TRACK = false, class TreeT>
-    RCX_DEV u32 step(const TreeT& tree, const DivEntry& k, bool last, u32 index = 0, u64 stream_len = 0)
+    // stream bytes consumed so far, header included (for the truncation check, cpprcoder.h:901-903)
+    RCX_DEV u64 taken() const { return 8 + (u64)((next - 4) - body) - (navail8 >> 3); }
+
+    // cpprcoder.h:926-940: shift in the bytes that bring range back above 2^24.  The window is
+    // topped up from `ahead`, whose replacement is requested right away and not needed before
+    // the next top-up (a few symbols later), so no load latency is exposed here.
+    RCX_DEV void pull()
     {
-        if (navail8 <= 32) refill();
-        // cpprcoder.h:926-940
+        if (navail8 <= 32) {
+            win |= (u64)rcx_bswap(ahead) << (32 - navail8);
+            navail8 += 32;
+            ahead = load_raw(next);
+            next += 4;
+        }
         const u32 k8 = rcx_clz(range) & 0x18u;
         low = (u32)((((u64)low << 32) | (u32)(win >> 32)) << k8 >> 32);
         win <<= k8;
         navail8 -= k8;
         range <<= k8;
-        taken += k8 >> 3;
-        if (TRACK && taken > stream_len && short_at == 0xFFFFFFFFu) short_at = index; // cpprcoder.h:901-903
+    }
 
-        const u32 total = k.total;
+    // Decodes one symbol (one lane per block).
+    template <bool TRACK = false, class TreeT>
+    RCX_DEV u32 step(const TreeT& tree, const DivEntry& k, u32 index = 0, u64 stream_len = 0)
+    {
+        // the top two tree levels sit at fixed addresses: ask for them before anything else
+        const U4 g3 = tree.group(RCX_G_L3);
+        const U4 q0 = tree.group(RCX_G_L2 + 0), q1 = tree.group(RCX_G_L2 + 1);
+        const U4 q2 = tree.group(RCX_G_L2 + 2), q3 = tree.group(RCX_G_L2 + 3);
+        RCX_DSTAMP(0); // since the end of the previous symbol (loop glue, divisor fetch, the five reads issued)
+        pull();
+        RCX_DSTAMP(1);
+        if (TRACK && taken() > stream_len && short_at == 0xFFFFFFFFu) short_at = index; // cpprcoder.h:901-903
+
         const u32 t = rcx_div(range, k); // :904
-        // :905 target = low / t.  A target >= total (corrupt input) falls through the
-        // reference's find() with code 0 and count = total (cpprcoder.h:1220-1242).
-        const bool off_table = low >= rcx_mul24(total, t);
-        u32 q = (u32)((float)low * rcx_rcp((float)t));
-        {
-            u32 back = low - rcx_mul24(q, t);
-            if ((s32)back < 0) q -= 1;
-            else if (back >= t) q += 1;
-        }
-
-        u32 rem = q, cum = 0, c = 0, f;
-        U4 g = tree.group(RCX_G_L3);
-        u32 p;
-#define RCX_DESCEND()                                                  \
-    {                                                                  \
-        const u32 a = g.x, b = a + g.y, d = b + g.z;                   \
-        u32 base = 0;                                                  \
-        p = 0;                                                         \
-        if (rem >= a) { base = a; p = 1; }                             \
-        if (rem >= b) { base = b; p = 2; }                             \
-        if (rem >= d) { base = d; p = 3; }                             \
-        rem -= base;                                                   \
-        cum += base;                                                   \
-        c = (c << 2) | p;                                              \
+        const u32 top = rcx_mul24(k.total, t);
+        u32 rem = low, c = 0, p, hit;
+        U4 g = g3;
+        // one level: which of the 4 children holds rem, what is left of rem below it, and the
+        // child's own count (`hit`, needed to store count+1 back without an LDS atomic)
+#define RCX_DESCEND()                                                          \
+    {                                                                          \
+        const u32 s2 = g.x + g.y, s3 = s2 + g.z;                               \
+        const u32 a = rcx_mul24(g.x, t), b = rcx_mul24(s2, t), d = rcx_mul24(s3, t); \
+        u32 base = 0;                                                          \
+        p = 0;                                                                 \
+        hit = g.x;                                                             \
+        if (rem >= a) { base = a; p = 1; hit = g.y; }                          \
+        if (rem >= b) { base = b; p = 2; hit = g.z; }                          \
+        if (rem >= d) { base = d; p = 3; hit = g.w; }                          \
+        rem -= base;                                                           \
+        c = (c << 2) | p;                                                      \
     }
         RCX_DESCEND();
-        g = tree.group(RCX_G_L2 + c);
+        const u32 c3 = c, hit3 = hit;
+        {
+            const U4 lo = (p & 1) ? q1 : q0, hi = (p & 1) ? q3 : q2;
+            g = (p & 2) ? hi : lo;
+        }
         RCX_DESCEND();
+        const u32 c2 = c, hit2 = hit;
+        RCX_DSTAMP(2); // divide + the two register-resident levels
         g = tree.group(RCX_G_L1 + c);
         RCX_DESCEND();
+        const u32 c1 = c, hit1 = hit;
+        RCX_DSTAMP(3); // level 1 (dependent LDS read)
         g = tree.group(RCX_G_L0 + c);
         RCX_DESCEND();
+        RCX_DSTAMP(4); // level 0 (dependent LDS read)
 #undef RCX_DESCEND
-        f = rcx_sel4(g, p);
-        if (off_table) {
+        u32 f = hit;
+        // A target at or past total (corrupt input) falls through the reference's find() with
+        // code 0 and count = total (cpprcoder.h:1220-1242).
+        if (low >= top) {
             RCX_SIM_COUNT(2, 1);
             c = 0;
-            cum = total;
+            rem = low - top;
             f = tree.group(RCX_G_L0).x;
         }
-        low -= rcx_mul24(cum, t);   // :906
-        range = rcx_mul24(f, t);    // :907
-        if (!last) tree.update(c);  // :912-916 the last symbol returns before update
+        const bool off_table = low >= top;
+        low = rem;                // :906
+        range = rcx_mul24(f, t);  // :907
+        // :916 +1 on the path to the leaf (after the last symbol the table is never looked at again)
+#if defined(RCX_ABLATE_DUPDATE) /* timing experiments only */
+        asm volatile("" ::"v"(hit3), "v"(hit2), "v"(hit1), "v"(c3), "v"(c2), "v"(c1), "v"(off_table));
+        if (false) {
+#else
+        if (off_table) {
+#endif
+            tree.update(0);
+        } else {
+            tree.put(RCX_G_L3, c3, hit3 + 1);
+            tree.put(RCX_G_L2 + c3, c2 & 3, hit2 + 1);
+            tree.put(RCX_G_L1 + c2, c1 & 3, hit1 + 1);
+            tree.put(RCX_G_L0 + c1, c & 3, f + 1);
+        }
+        RCX_DSTAMP(5); // tail: f, low/range, the four ds_add
         return c;
     }
 };

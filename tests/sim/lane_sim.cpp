@@ -65,7 +65,7 @@ int sim_encode_blocks(const uint8_t* src, uint64_t n, uint32_t block, uint8_t* s
         Tree tree{lds.data() + lane};
         tree.reset();
         EncLane e;
-        e.begin(slots + b * slot, (u32)slot, len);
+        e.begin(slots, (u32)(b * slot), (u32)slot, len);
         for (uint32_t i = 0; i < len; ++i) e.step(tree, src[at + i], tab[i]);
         sizes[b] = e.finish();
         overflow |= (int)e.overflow;
@@ -82,7 +82,7 @@ void sim_stream_encode_track(const uint8_t* src, uint32_t n, uint64_t sink16, ui
     Tree tree{lds.data() + 3};
     tree.reset();
     EncLane e;
-    e.begin(slot, (u32)slot_bytes, n);
+    e.begin(slot, 0, (u32)slot_bytes, n);
     e.trk_cap = (u32)(sink16 - 4);
     for (uint32_t i = 0; i < n; ++i) e.step<true>(tree, src[i], rcx_make_div_entry(256 + i), i);
     out[0] = e.trk_fail_at;
@@ -103,7 +103,7 @@ uint32_t sim_stream_decode_track(const uint8_t* comp, uint64_t comp_size, uint32
     memcpy(base, comp, comp_size);
     DecLane d;
     d.begin(base, base + comp_size);
-    for (uint32_t i = 0; i < count; ++i) dst[i] = (uint8_t)d.step<true>(tree, rcx_make_div_entry(256 + i), i + 1 == count, i, comp_size);
+    for (uint32_t i = 0; i < count; ++i) dst[i] = (uint8_t)d.step<true>(tree, rcx_make_div_entry(256 + i), i, comp_size);
     return d.short_at;
 }
 
@@ -131,8 +131,8 @@ uint64_t sim_decode_blocks(const uint8_t* comp, const uint64_t* offsets, uint64_
         memcpy(base, comp + s0, s1 - s0);
         u32 declared = d.begin(base, base + (s1 - s0));
         if (declared != len) return b + 1;
-        for (uint32_t i = 0; i < len; ++i) dst[at + i] = (uint8_t)d.step(tree, tab[i], i + 1 == len);
-        if (d.taken > s1 - s0) return b + 1;
+        for (uint32_t i = 0; i < len; ++i) dst[at + i] = (uint8_t)d.step(tree, tab[i]);
+        if (d.taken() > s1 - s0) return b + 1;
     }
     return 0;
 }

@@ -216,7 +216,7 @@ def test_single_stream_semantics(ctx, oracle, golden):
     assert hashlib.sha256(out).hexdigest() == pins["decode_truncated"]["out_sha256"]
     st, rq, out = ctx.stream_decode(comp, r16(1000))
     assert [st, rq] == pins["decode_sink_full"]["status"] and len(out) == pins["decode_sink_full"]["size"]
-    assert hashlib.sha256(out).hexdigest() == pins["decode_sink_full"]["out_sha256"]
+    assert hashlib.sha256(out[:1000]).hexdigest() == pins["decode_sink_full"]["out_sha256"]  # the fixture hashed the first 1000 bytes
 
 
 def test_full_size_properties(ctx, oracle):
