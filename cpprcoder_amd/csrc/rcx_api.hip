@@ -33,7 +33,7 @@ struct EventPair {
 
 struct rcx_ctx {
     int device = 0;
-    int lanes_per_block = 1; // decode: 1 = one lane per block, 8 = octet kernel (RCX_LANES_PER_BLOCK)
+    int lanes_per_block = 8; // decode: 8 = octet kernel (default), 1 = one lane per block (RCX_LANES_PER_BLOCK)
     int enc_variant = 2;     // encode: 0 = one lane per block, 1 = octet, 2 = model/coder wave split (RCX_ENC_VARIANT)
     // scratch
     u8* slots = nullptr;
@@ -179,7 +179,7 @@ int rcx_ctx_create(int device, rcx_ctx** out)
     rcx_ctx* c = new (std::nothrow) rcx_ctx();
     if (!c) return RCX_E_NOMEM;
     c->device = device;
-    if (const char* v = getenv("RCX_LANES_PER_BLOCK")) c->lanes_per_block = atoi(v) == 8 ? 8 : 1;
+    if (const char* v = getenv("RCX_LANES_PER_BLOCK")) c->lanes_per_block = atoi(v) == 1 ? 1 : 8;
     if (const char* v = getenv("RCX_ENC_VARIANT")) c->enc_variant = atoi(v) >= 0 && atoi(v) <= 2 ? atoi(v) : 2;
     if (hipMalloc(reinterpret_cast<void**>(&c->status), 4 * sizeof(u32)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&c->status_host), 4 * sizeof(u32), hipHostMallocDefault) != hipSuccess) {

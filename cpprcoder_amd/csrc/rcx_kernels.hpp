@@ -44,6 +44,8 @@ __device__ __forceinline__ u32 rcx_byte_of(const U4& w, u32 j)
 
 // LDS image of one wave: the 64 lane-interleaved trees, then 64 staged divisor entries.
 #define RCX_LDS_U4 ((RCX_GROUPS + 1) * RCX_LANES)
+// the decoder adds the 64 input rings (RCX_RING_DW dwords per lane, dword-interleaved)
+#define RCX_DEC_LDS_U4 (RCX_LDS_U4 + RCX_RING_DW * RCX_LANES / 4)
 
 // ===========================================================================
 // Encode, pass 1
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ 
                                                          u32 block, u64 n, u8* __restrict__ dst,
                                                          const DivEntry* __restrict__ divtab, u32* status, u32* track)
 {
-    __shared__ U4 lds[RCX_LDS_U4];
+    __shared__ U4 lds[RCX_DEC_LDS_U4];
     const u32 lane = threadIdx.x;
     const u64 blk = (u64)blockIdx.x * RCX_LANES + lane;
     bool live = blk < nblocks;
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ 
     Tree tree{lds + lane};
     tree.reset();
     DivEntry* stage = reinterpret_cast<DivEntry*>(lds + RCX_GROUPS * RCX_LANES);
+    u32* ring_col = reinterpret_cast<u32*>(lds + RCX_LDS_U4) + lane;
 
     DecLane dec;
 #if defined(RCX_STAMP_DEC)
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ 
             live = false;
             len = 0;
         } else {
-            const u32 declared = dec.begin(comp + s0, comp + s1);
+            const u32 declared = dec.begin(comp + s0, comp + s1, ring_col);
             if (!STREAM && declared != len) { // the layout says len; a header that disagrees is not ours
                 rcx_flag(status, RCX_ST_CORRUPT, blk);
                 live = false;
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ 
             }
         }
     }
-    if (!live) dec.idle(comp);
+    if (!live) dec.idle(comp, ring_col);
 
     const u32 maxlen = rcx_wave_max(len);
     const bool full = !STREAM && __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
@@ -252,6 +255,7 @@ __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ 
             for (u32 j0 = 0; j0 < jend; j0 += 16) {
                 const u32 i = i0 + j0;
                 u32 word[4] = {0, 0, 0, 0};
+                dec.topup();
                 DivEntry k_next = stage[j0]; // divisor of the next symbol: fetched one symbol early
 #pragma unroll
                 for (u32 j = 0; j < 16; ++j) {
@@ -276,6 +280,7 @@ __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ 
             for (u32 j = 0; j < jend; ++j) {
                 const u32 i = i0 + j;
                 const DivEntry k = stage[j];
+                if ((j & 15u) == 0) dec.topup();
                 if (i < len) out[i] = (u8)dec.template step<STREAM>(tree, k, i, stream_len);
             }
         }

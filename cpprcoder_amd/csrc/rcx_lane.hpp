@@ -51,6 +51,7 @@ struct alignas(16) U4 {
 #define RCX_G_L0 21
 #define RCX_GROUPS 85
 #define RCX_STAGE 64 /* divisor-table entries staged per refill */
+#define RCX_RING_DW 32 /* decoder: dwords of compressed stream buffered per block in LDS */
 
 // One divisor-table entry for total = 256 + index:
 //   floor(n / total) == (u32)(((u64)n * mul + add) >> 32) >> shift   for all n < 2^32
@@ -73,6 +74,9 @@ RCX_DEV u32 rcx_perm(u32 hi, u32 lo, u32 sel)
 RCX_DEV u32 rcx_bswap(u32 x) { return __builtin_bswap32(x); }
 RCX_DEV void rcx_lds_inc(u32* p) { *p += 1; }
 RCX_DEV float rcx_rcp(float x) { return 1.0f / x; }
+RCX_DEV bool rcx_any(bool p) { return p; }
+RCX_DEV u32 rcx_funnel_shr(u32 hi, u32 lo, u32 sh) { return (u32)(((((u64)hi) << 32) | lo) >> (sh & 31u)); }
+#define RCX_COLD inline
 // coverage counters of the host simulator: [0] carries that left the register window,
 // [1] bytes touched by those, [2] decoder symbols on the off-table (corrupt) path
 extern uint64_t rcx_sim_counters[4];
@@ -86,6 +90,9 @@ RCX_DEV u32 rcx_bswap(u32 x) { return __builtin_bswap32(x); }
 RCX_DEV void rcx_lds_inc(u32* p) { (void)__hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 RCX_DEV void rcx_lds_add(u32* p, u32 v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 RCX_DEV float rcx_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+RCX_DEV bool rcx_any(bool p) { return __builtin_expect(__any(p) != 0, 0); } // wave-uniform: some lane has p
+RCX_DEV u32 rcx_funnel_shr(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); } // ({hi,lo} >> sh) low half
+#define RCX_COLD __device__ __attribute__((noinline, cold))
 #endif
 
 #if defined(RCX_ABLATE_DIV) /* timing experiments only */
@@ -138,6 +145,22 @@ RCX_DEV u32 rcx_sel4(const U4& g, u32 p)
     u32 hi = (p & 1) ? g.w : g.z;
     return (p & 2) ? hi : lo;
 }
+
+// Add `extra` into the `count` payload bytes already stored, from the newest backwards
+// (cpprcoder.h:767-781 when the carry leaves the bytes held in registers).  Rare: ~9e-5 per symbol.
+RCX_DEV void rcx_carry_walk(u8* out, u32 count, u32 extra)
+{
+    if (count && extra) RCX_SIM_COUNT(0, 1);
+    while (count > 0 && extra) {
+        --count;
+        RCX_SIM_COUNT(1, 1);
+        u32 v = (u32)out[count] + extra;
+        out[count] = (u8)v;
+        extra = v >> 8;
+    }
+}
+// out of line, by value: keeps the coder's registers out of memory on the hot path
+RCX_COLD void rcx_carry_slow(u8* out, u32 count, u32 extra) { rcx_carry_walk(out, count, extra); }
 
 // ---------------------------------------------------------------------------
 // Encoder lane.
@@ -210,32 +233,7 @@ struct EncLane {
     }
 
     // `extra` carries ran through every byte held in acc: continue in memory (cpprcoder.h:767-781)
-    RCX_DEV void carry_into_memory(u32 extra)
-    {
-        u32 p = leader ? (pos < cap ? pos : 0) : 0;
-        u8* out = payload();
-        RCX_SIM_COUNT(0, 1);
-        while (p > 0 && extra) {
-            --p;
-            RCX_SIM_COUNT(1, 1);
-            u32 v = (u32)out[p] + extra;
-            out[p] = (u8)v;
-            extra = v >> 8;
-        }
-    }
-
-    RCX_DEV void store4(u32 word_le)
-    {
-        const bool ok = pos + 4 <= cap;
-        const u32 where = ok ? pos : cap - 4; // a too-small slot keeps overwriting its last word
-        overflow |= ok ? 0u : 1u;
-#if !defined(RCX_ABLATE_STORE) /* timing experiments only: never defined in a shipped build */
-        if (leader) *reinterpret_cast<u32*>(base + (off + where)) = word_le;
-#else
-        asm volatile("" ::"v"(word_le), "v"(where));
-#endif
-        pos += 4;
-    }
+    RCX_DEV void carry_into_memory(u32 extra) { rcx_carry_walk(base + off, leader ? (pos < cap ? pos : 0u) : 0u, extra); }
 
     // TRACK: replay cpprcoder.h:767-800 on counters only.  `moved` is low after the add,
     // k8 the renormalisation shift of this symbol.
@@ -286,24 +284,38 @@ struct EncLane {
         range <<= k8;
         nacc8 += k8;
 #if !defined(RCX_ABLATE_FLUSH)
-        if (nacc8 >= 40) flush();
+        flush();
 #else
         nacc8 &= 31u;
 #endif
     }
 
-    // 5..7 bytes held: store the 4 oldest, keep 1..3
+    // With 5..7 bytes held: store the 4 oldest, keep 1..3.  Some lane of a wave is in that state on
+    // almost every symbol, so this runs for all lanes without a branch: everything is computed and
+    // selected, the store is the only predicated piece, and the carry-ran-off-the-register case is
+    // one wave-uniform, normally not taken test.  `pos` may run past `cap` (the store address is
+    // clamped, so a too-small slot keeps overwriting its last word); finish() reports that.
     RCX_DEV void flush()
     {
-        const u32 keep8 = nacc8 - 32;
-        const u64 top = acc >> keep8; // 4 oldest bytes, and above them any carry that ran off the held bytes
-        const u32 extra = (u32)(top >> 32);
-        if (extra) carry_into_memory(extra);
-        store4(rcx_bswap((u32)top));
-        acc &= ((u64)1 << keep8) - 1;
-        nacc8 = keep8;
+        const bool due = nacc8 >= 40;
+        const u32 keep8 = (nacc8 - 32) & 31u;                    // 8, 16 or 24 when due
+        const u32 acc_lo = (u32)acc, acc_hi = (u32)(acc >> 32);
+        const u32 word = rcx_funnel_shr(acc_hi, acc_lo, keep8);  // the 4 oldest bytes
+        const u32 extra = due ? acc_hi >> keep8 : 0u;            // a carry that ran off the held bytes
+        if (rcx_any(extra != 0)) rcx_carry_slow(base + off, leader ? (pos < cap ? pos : 0u) : 0u, extra);
+        const u32 where = pos < cap - 4 ? pos : cap - 4;
+        if (due && leader) {
+#if !defined(RCX_ABLATE_STORE) /* timing experiments only: never defined in a shipped build */
+            *reinterpret_cast<u32*>(base + (off + where)) = rcx_bswap(word);
+#else
+            asm volatile("" ::"v"(word), "v"(where));
+#endif
+        }
+        const u32 kept = acc_lo & ((1u << keep8) - 1u);
+        acc = due ? (u64)kept : acc;
+        nacc8 -= due ? 32u : 0u;
+        pos += due ? 4u : 0u;
     }
-
     // One lane per block: model query, code, model update.
     template <bool TRACK = false, class TreeT>
     RCX_DEV void step(const TreeT& tree, u32 c, const DivEntry& k, u32 index = 0)
@@ -321,6 +333,7 @@ struct EncLane {
     // cpprcoder.h:744-762: the held bytes, then low big-endian.  Returns the stream size.
     RCX_DEV u32 finish()
     {
+        if (pos > cap) overflow = 1; // flush() clamps its stores instead of testing
         const u32 extra = (u32)(acc >> nacc8);
         if (extra) carry_into_memory(extra);
         const u32 n = nacc8 >> 3;
@@ -353,9 +366,17 @@ struct DecLane {
     u32 low, range;
     u64 win;            // upcoming stream bytes, left-aligned (next byte on top)
     u32 navail8;        // 8 * bytes in win
-    u32 ahead;          // the dword after the window, loaded one refill early; kept RAW (memory order) so that
-                        // nothing touches it -- and waits for the load -- before the next refill
-    const u8* next;     // the aligned dword after `ahead`
+    u32 ahead;          // the dword after the window, fetched from the ring one refill early; RAW (memory
+                        // order) so that nothing touches it -- and waits for it -- before the next refill
+    // The compressed stream reaches the window through a per-lane ring of RCX_RING_DW dwords in LDS that
+    // is topped up every 16 symbols with 16-byte global loads issued one top-up ahead.  (Loading the
+    // window straight from global memory puts a vmcnt wait -- which also waits for the older output
+    // stores -- into every symbol: measured 430 cycles per symbol.)
+    u32* ring;          // this lane's ring column: dword d lives at ring[(d % RCX_RING_DW) * RCX_LANES]
+    u32 rd, wr;         // dwords taken from / written to the ring so far, counted from `origin`
+    const u8* origin;   // 16-byte aligned address of ring dword 0
+    U4 pend0, pend1, pend2, pend3; // pieces requested at the previous top-up, not yet in the ring
+    u32 npend;
     const u8* body;     // first stream byte after the 8 header bytes
     const u8* end;      // one past the block's stream
     u32 short_at;       // TRACK only: first symbol whose normalize ran past the input, or 0xFFFFFFFF
@@ -375,57 +396,102 @@ struct DecLane {
 #define RCX_DSTAMP(i)
 #endif
 
+    // 16 aligned bytes; a piece that starts at or past the end of the stream is zeros (one that
+    // merely straddles the end stays inside the page that holds the stream's last byte)
+    RCX_DEV U4 load16(const u8* p) const
+    {
+        U4 z;
+        z.x = z.y = z.z = z.w = 0;
 #if defined(RCX_ABLATE_DLOAD) /* timing experiments only */
-    RCX_DEV u32 load_raw(const u8* p) const { return (u32)(uintptr_t)p * 2654435761u; }
+        z.x = (u32)(uintptr_t)p;
+        return z;
 #else
-    RCX_DEV u32 load_raw(const u8* p) const { return p < end ? *reinterpret_cast<const u32*>(p) : 0u; }
+        return p < end ? *reinterpret_cast<const U4*>(p) : z;
 #endif
+    }
+    RCX_DEV void ring_put(const U4& piece)
+    {
+        u32* at = ring + (wr % RCX_RING_DW) * RCX_LANES; // wr is a multiple of 4: the piece never wraps
+        at[0] = piece.x;
+        at[RCX_LANES] = piece.y;
+        at[2 * RCX_LANES] = piece.z;
+        at[3 * RCX_LANES] = piece.w;
+        wr += 4;
+    }
+    RCX_DEV u32 ring_get()
+    {
+        const u32 v = ring[(rd % RCX_RING_DW) * RCX_LANES];
+        rd += 1;
+        return v;
+    }
 
     // cpprcoder.h:877-896 + :859-870.  `s` points at the block's stream (any alignment),
     // which must be at least 8 bytes long.  Returns the declared size.
-    RCX_DEV u32 begin(const u8* s, const u8* stream_end)
+    RCX_DEV u32 begin(const u8* s, const u8* stream_end, u32* ring_column)
     {
         u32 declared = (u32)s[0] | ((u32)s[1] << 8) | ((u32)s[2] << 16) | ((u32)s[3] << 24);
         low = ((u32)s[4] << 24) | ((u32)s[5] << 16) | ((u32)s[6] << 8) | (u32)s[7];
         range = 0x00FFFFFFu;
         end = stream_end;
         body = s + 8;
+        ring = ring_column;
+        origin = body - ((uintptr_t)body & 15);
+        wr = 0;
+        for (u32 r = 0; r < 6; ++r) ring_put(load16(origin + 16 * r)); // prologue: 24 dwords, synchronously
+        npend = 0;
+        rd = (u32)(body - origin) >> 2;
         const u32 skew = (u32)((uintptr_t)body & 3);
-        next = body - skew;
-        win = (u64)(rcx_bswap(load_raw(next)) << (8 * skew)) << 32; // past the end: zeros
+        win = (u64)(rcx_bswap(ring_get()) << (8 * skew)) << 32;
         navail8 = 32 - 8 * skew;
-        next += 4;
-        ahead = load_raw(next);
-        next += 4;
+        ahead = ring_get();
         short_at = 0xFFFFFFFFu;
         return declared;
     }
 
     // a lane without a block
-    RCX_DEV void idle(const u8* anywhere)
+    RCX_DEV void idle(const u8* anywhere, u32* ring_column)
     {
         low = 0;
         range = 0x01000000u;
         win = 0;
         navail8 = 64;
         ahead = 0;
-        next = body = end = anywhere;
+        ring = ring_column;
+        rd = wr = 0;
+        npend = 0;
+        origin = body = end = anywhere;
         short_at = 0xFFFFFFFFu;
     }
 
+    // Every 16 symbols (a lane takes at most 13 dwords in that time): move the pieces requested
+    // last time into the ring, then request as many new ones as fit -- at most 4 = 16 dwords.
+    RCX_DEV void topup()
+    {
+        if (npend > 0) ring_put(pend0);
+        if (npend > 1) ring_put(pend1);
+        if (npend > 2) ring_put(pend2);
+        if (npend > 3) ring_put(pend3);
+        npend = 0;
+        u32 planned = wr;
+        // slots [rd, wr) are unread; slot rd-1 is already in `ahead`
+        if (planned + 4 - rd <= RCX_RING_DW) { pend0 = load16(origin + 4 * (size_t)planned); planned += 4; npend = 1; }
+        if (planned + 4 - rd <= RCX_RING_DW) { pend1 = load16(origin + 4 * (size_t)planned); planned += 4; npend = 2; }
+        if (planned + 4 - rd <= RCX_RING_DW) { pend2 = load16(origin + 4 * (size_t)planned); planned += 4; npend = 3; }
+        if (planned + 4 - rd <= RCX_RING_DW) { pend3 = load16(origin + 4 * (size_t)planned); planned += 4; npend = 4; }
+    }
+
     // stream bytes consumed so far, header included (for the truncation check, cpprcoder.h:901-903)
-    RCX_DEV u64 taken() const { return 8 + (u64)((next - 4) - body) - (navail8 >> 3); }
+    RCX_DEV u64 taken() const { return 8 + (u64)(4 * (size_t)(rd - 1)) - (u64)(body - origin) - (navail8 >> 3); }
 
     // cpprcoder.h:926-940: shift in the bytes that bring range back above 2^24.  The window is
-    // topped up from `ahead`, whose replacement is requested right away and not needed before
-    // the next top-up (a few symbols later), so no load latency is exposed here.
+    // topped up from `ahead`, whose replacement is requested from the ring right away and not
+    // needed before the next top-up (a few symbols later), so no latency is exposed here.
     RCX_DEV void pull()
     {
         if (navail8 <= 32) {
             win |= (u64)rcx_bswap(ahead) << (32 - navail8);
             navail8 += 32;
-            ahead = load_raw(next);
-            next += 4;
+            ahead = ring_get();
         }
         const u32 k8 = rcx_clz(range) & 0x18u;
         low = (u32)((((u64)low << 32) | (u32)(win >> 32)) << k8 >> 32);

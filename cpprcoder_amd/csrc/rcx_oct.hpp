@@ -26,6 +26,7 @@
 #define RCX_OCT_NODE_BYTES 128    /* 32 node sums */
 #define RCX_OCT_BLOCK_BYTES 1152  /* + 256 counts */
 #define RCX_OCT_LDS_BYTES (RCX_OCT_BLOCKS * RCX_OCT_BLOCK_BYTES + RCX_STAGE * 16)
+#define RCX_OCT_DEC_LDS_BYTES (RCX_OCT_LDS_BYTES + RCX_RING_DW * RCX_LANES * 4)
 
 template <int CTRL>
 __device__ __forceinline__ u32 rcx_dpp(u32 x)
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(64) void rcx_dec_oct_k(const u8* __restrict__ comp,
                                                     u32 block, u64 n, u8* __restrict__ dst,
                                                     const DivEntry* __restrict__ divtab, u32* status)
 {
-    __shared__ __attribute__((aligned(16))) u8 lds[RCX_OCT_LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) u8 lds[RCX_OCT_DEC_LDS_BYTES];
     const u32 lane = threadIdx.x;
     const u32 j = lane & 7u, oct = lane >> 3;
     const u64 blk = (u64)blockIdx.x * RCX_OCT_BLOCKS + oct;
@@ -188,6 +189,8 @@ __global__ __launch_bounds__(64) void rcx_dec_oct_k(const u8* __restrict__ comp,
     OctModel model;
     model.reset(lds + oct * RCX_OCT_BLOCK_BYTES, j);
     DivEntry* stage = reinterpret_cast<DivEntry*>(lds + RCX_OCT_BLOCKS * RCX_OCT_BLOCK_BYTES);
+    // every lane keeps its own copy of the octet's input ring (8 identical columns: no cross-lane ordering needed)
+    u32* ring_col = reinterpret_cast<u32*>(lds + RCX_OCT_LDS_BYTES) + lane;
     const u32 m1 = (j & 1u) ? ~0u : 0u, m2 = (j & 2u) ? ~0u : 0u, m4 = (j & 4u) ? ~0u : 0u;
 
     DecLane dec;
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(64) void rcx_dec_oct_k(const u8* __restrict__ comp,
             live = false;
             len = 0;
         } else {
-            const u32 declared = dec.begin(comp + s0, comp + s1);
+            const u32 declared = dec.begin(comp + s0, comp + s1, ring_col);
             if (declared != len) {
                 if (j == 0) rcx_flag(status, RCX_ST_CORRUPT, blk);
                 live = false;
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(64) void rcx_dec_oct_k(const u8* __restrict__ comp,
             }
         }
     }
-    if (!live) dec.idle(comp);
+    if (!live) dec.idle(comp, ring_col);
 
     const u32 maxlen = rcx_wave_max(len);
     const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
@@ -264,6 +267,7 @@ __global__ __launch_bounds__(64) void rcx_dec_oct_k(const u8* __restrict__ comp,
             for (u32 j0 = 0; j0 < jend; j0 += 16) {
                 const u32 i = i0 + j0;
                 u32 word[4] = {0, 0, 0, 0};
+                dec.topup();
                 DivEntry k_next = stage[j0];
 #pragma unroll
                 for (u32 s = 0; s < 16; ++s) {
@@ -291,6 +295,7 @@ __global__ __launch_bounds__(64) void rcx_dec_oct_k(const u8* __restrict__ comp,
             for (u32 s = 0; s < jend; ++s) {
                 const u32 i = i0 + s;
                 const DivEntry k = stage[s];
+                if ((s & 15u) == 0) dec.topup();
                 if (i < len) {
                     u32 sym;
                     RCX_OCT_DEC_SYMBOL(k, sym);

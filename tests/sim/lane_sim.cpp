@@ -96,14 +96,18 @@ uint32_t sim_stream_decode_track(const uint8_t* comp, uint64_t comp_size, uint32
     std::vector<U4> lds((RCX_GROUPS + 1) * RCX_LANES);
     Tree tree{lds.data() + 9};
     tree.reset();
-    std::vector<uint8_t> pad(comp_size + 32);
+    std::vector<uint8_t> pad(comp_size + 64);
     uint8_t* base = pad.data();
-    while (((uintptr_t)base & 3) != 0) ++base;
-    base += 4;
+    while (((uintptr_t)base & 15) != 0) ++base;
+    base += 16 + 5; // any alignment will do; 5 exercises the skewed start
     memcpy(base, comp, comp_size);
+    std::vector<u32> ringmem(RCX_RING_DW * RCX_LANES);
     DecLane d;
-    d.begin(base, base + comp_size);
-    for (uint32_t i = 0; i < count; ++i) dst[i] = (uint8_t)d.step<true>(tree, rcx_make_div_entry(256 + i), i, comp_size);
+    d.begin(base, base + comp_size, ringmem.data() + 9);
+    for (uint32_t i = 0; i < count; ++i) {
+        if ((i & 15u) == 0) d.topup();
+        dst[i] = (uint8_t)d.step<true>(tree, rcx_make_div_entry(256 + i), i, comp_size);
+    }
     return d.short_at;
 }
 
@@ -121,17 +125,21 @@ uint64_t sim_decode_blocks(const uint8_t* comp, const uint64_t* offsets, uint64_
         Tree tree{lds.data() + lane};
         tree.reset();
         DecLane d;
-        // the device code loads aligned dwords that may start before / end after the stream:
+        // the device code loads aligned 16-byte pieces that may start before / end after the stream:
         // give it a padded private copy at the same alignment
-        std::vector<uint8_t> pad(s1 - s0 + 16);
-        uint32_t skew = (uint32_t)(s0 & 3);
+        std::vector<uint8_t> pad(s1 - s0 + 64);
+        uint32_t skew = (uint32_t)(s0 & 15);
         uint8_t* base = pad.data();
-        while (((uintptr_t)base & 3) != 0) ++base;
-        base += skew + 4;
+        while (((uintptr_t)base & 15) != 0) ++base;
+        base += 16 + skew;
         memcpy(base, comp + s0, s1 - s0);
-        u32 declared = d.begin(base, base + (s1 - s0));
+        std::vector<u32> ringmem(RCX_RING_DW * RCX_LANES);
+        u32 declared = d.begin(base, base + (s1 - s0), ringmem.data() + lane);
         if (declared != len) return b + 1;
-        for (uint32_t i = 0; i < len; ++i) dst[at + i] = (uint8_t)d.step(tree, tab[i]);
+        for (uint32_t i = 0; i < len; ++i) {
+            if ((i & 15u) == 0) d.topup();
+            dst[at + i] = (uint8_t)d.step(tree, tab[i]);
+        }
         if (d.taken() > s1 - s0) return b + 1;
     }
     return 0;
