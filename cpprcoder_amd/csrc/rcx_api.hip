@@ -33,7 +33,7 @@ struct EventPair {
 
 struct rcx_ctx {
     int device = 0;
-    int lanes_per_block = 8; // decode: 8 = octet kernel (default), 1 = one lane per block (RCX_LANES_PER_BLOCK)
+    int lanes_per_block = 8; // decode: 8 = octet kernel (default, fastest measured), 4 = quad, 1 = one lane per block (RCX_LANES_PER_BLOCK)
     int enc_variant = 2;     // encode: 0 = one lane per block, 1 = octet, 2 = model/coder wave split (RCX_ENC_VARIANT)
     // scratch
     u8* slots = nullptr;
@@ -179,7 +179,7 @@ int rcx_ctx_create(int device, rcx_ctx** out)
     rcx_ctx* c = new (std::nothrow) rcx_ctx();
     if (!c) return RCX_E_NOMEM;
     c->device = device;
-    if (const char* v = getenv("RCX_LANES_PER_BLOCK")) c->lanes_per_block = atoi(v) == 1 ? 1 : 8;
+    if (const char* v = getenv("RCX_LANES_PER_BLOCK")) c->lanes_per_block = (atoi(v) == 1 || atoi(v) == 4) ? atoi(v) : 8;
     if (const char* v = getenv("RCX_ENC_VARIANT")) c->enc_variant = atoi(v) >= 0 && atoi(v) <= 2 ? atoi(v) : 2;
     if (hipMalloc(reinterpret_cast<void**>(&c->status), 4 * sizeof(u32)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&c->status_host), 4 * sizeof(u32), hipHostMallocDefault) != hipSuccess) {
@@ -299,7 +299,11 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
     if (r != RCX_OK) return r;
     {
         Timed t(c, s, RCX_T_DECODE);
-        if (c->lanes_per_block == 8) {
+        if (c->lanes_per_block == 4) {
+            const u32 grid = (u32)((nblocks + RCX_QUAD_BLOCKS - 1) / RCX_QUAD_BLOCKS);
+            hipLaunchKernelGGL(rcx_dec_quad_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
+                               block, n, static_cast<u8*>(d_dst), c->divtab, c->status);
+        } else if (c->lanes_per_block == 8) {
             const u32 grid = (u32)((nblocks + RCX_OCT_BLOCKS - 1) / RCX_OCT_BLOCKS);
             hipLaunchKernelGGL(rcx_dec_oct_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
                                block, n, static_cast<u8*>(d_dst), c->divtab, c->status);

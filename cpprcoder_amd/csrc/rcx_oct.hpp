@@ -537,3 +537,184 @@ __global__ __launch_bounds__(RCX_MC_THREADS) void rcx_enc_mc_k(const u8* __restr
         if (enc.overflow) rcx_flag(status, RCX_ST_CAPACITY, blk);
     }
 }
+
+// ===========================================================================
+// Decode, 4 lanes per block ("quad"): 16 blocks per wave, 1024 waves for 1 GiB of 64 KiB
+// blocks = one wave per SIMD.  Same scheme as the octet decoder with a 16 x 16 split of the
+// alphabet: lane j owns the node sums 4j..4j+3 (16 symbols each, fixed LDS address) and keeps
+// `before` = the sum of the nodes of lanes < j; round 1 finds the node (each lane tests its 4),
+// round 2 the symbol among the node's 16 (each lane reads 4 counts, one ds_read_b128).
+// An instruction costs a SIMD 4 cycles whether it serves 8 or 16 blocks, so halving the lanes
+// per block halves the machine-wide instruction work of the octet kernel.
+// ===========================================================================
+#define RCX_QUAD_BLOCKS 16
+#define RCX_QUAD_BLOCK_BYTES 1088 /* 16 node sums + 256 counts */
+#define RCX_QUAD_LDS_BYTES (RCX_QUAD_BLOCKS * RCX_QUAD_BLOCK_BYTES + RCX_STAGE * 16 + RCX_RING_DW * RCX_LANES * 4)
+
+__device__ __forceinline__ u32 rcx_quad_sum(u32 x)
+{
+    x += rcx_dpp<0xB1>(x); // quad_perm [1,0,3,2]
+    x += rcx_dpp<0x4E>(x); // quad_perm [2,3,0,1]
+    return x;
+}
+__device__ __forceinline__ u32 rcx_quad_excl_scan(u32 x, u32 m1, u32 m2)
+{
+    u32 o = rcx_dpp<0xB1>(x);
+    u32 pre = o & m1;
+    const u32 tot = x + o;
+    o = rcx_dpp<0x4E>(tot);
+    pre += o & m2;
+    return pre;
+}
+
+__global__ __launch_bounds__(64) void rcx_dec_quad_k(const u8* __restrict__ comp, const u64* __restrict__ offsets, u64 nblocks,
+                                                     u32 block, u64 n, u8* __restrict__ dst,
+                                                     const DivEntry* __restrict__ divtab, u32* status)
+{
+    __shared__ __attribute__((aligned(16))) u8 lds[RCX_QUAD_LDS_BYTES];
+    const u32 lane = threadIdx.x;
+    const u32 j = lane & 3u, quad = lane >> 2;
+    const u64 blk = (u64)blockIdx.x * RCX_QUAD_BLOCKS + quad;
+    bool live = blk < nblocks;
+    const u64 at = live ? blk * (u64)block : 0;
+    u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
+
+    // model: cpprcoder.h:1094-1132, every count 1
+    u8* mine = lds + quad * RCX_QUAD_BLOCK_BYTES;
+    U4* nodes = reinterpret_cast<U4*>(mine) + j;
+    U4* leaves = reinterpret_cast<U4*>(mine + 64);
+    {
+        U4 v;
+        v.x = v.y = v.z = v.w = 16;
+        *nodes = v;
+        v.x = v.y = v.z = v.w = 1;
+#pragma unroll
+        for (u32 q = 0; q < 16; ++q) leaves[q * 4 + j] = v;
+    }
+    u32 before = 64u * j;
+    DivEntry* stage = reinterpret_cast<DivEntry*>(lds + RCX_QUAD_BLOCKS * RCX_QUAD_BLOCK_BYTES);
+    u32* ring_col = reinterpret_cast<u32*>(lds + RCX_QUAD_BLOCKS * RCX_QUAD_BLOCK_BYTES + RCX_STAGE * 16) + lane;
+    const u32 m1 = (j & 1u) ? ~0u : 0u, m2 = (j & 2u) ? ~0u : 0u;
+
+    DecLane dec;
+    u64 stream_len = 0;
+    if (live) {
+        const u64 s0 = offsets[blk], s1 = offsets[blk + 1];
+        stream_len = s1 - s0;
+        if (s1 < s0 || stream_len < 9) {
+            if (j == 0) rcx_flag(status, RCX_ST_CORRUPT, blk);
+            live = false;
+            len = 0;
+        } else {
+            const u32 declared = dec.begin(comp + s0, comp + s1, ring_col);
+            if (declared != len) {
+                if (j == 0) rcx_flag(status, RCX_ST_CORRUPT, blk);
+                live = false;
+                len = 0;
+            }
+        }
+    }
+    if (!live) dec.idle(comp, ring_col);
+
+    const u32 maxlen = rcx_wave_max(len);
+    const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+    u8* out = dst + at;
+    const bool leader = live && j == 0;
+
+    // One symbol; all comparisons in the scaled domain (see DecLane).
+#define RCX_QUAD_DEC_SYMBOL(K, SYM)                                                                        \
+    {                                                                                                      \
+        const U4 g_ = *nodes;                                                                              \
+        dec.pull();                                                                                        \
+        const DivEntry k_ = (K);                                                                           \
+        const u32 t_ = rcx_div(dec.range, k_);                                                             \
+        const u32 top_ = rcx_mul24(k_.total, t_);                                                          \
+        /* round 1: which of the 16 nodes */                                                               \
+        const u32 d_ = dec.low - rcx_mul24(before, t_);                                                    \
+        const u32 s2_ = g_.x + g_.y, s3_ = s2_ + g_.z, s4_ = s3_ + g_.w;                                   \
+        const u32 a_ = rcx_mul24(g_.x, t_), b_ = rcx_mul24(s2_, t_), c_ = rcx_mul24(s3_, t_);              \
+        const u32 e_ = rcx_mul24(s4_, t_);                                                                 \
+        u32 p_ = 0, base_ = 0;                                                                             \
+        if (d_ >= a_) { p_ = 1; base_ = a_; }                                                              \
+        if (d_ >= b_) { p_ = 2; base_ = b_; }                                                              \
+        if (d_ >= c_) { p_ = 3; base_ = c_; }                                                              \
+        const bool own1_ = d_ < e_;                                                                        \
+        const u32 node_ = rcx_quad_sum(own1_ ? 4u * j + p_ : 0u);                                          \
+        const u32 rem_ = rcx_quad_sum(own1_ ? d_ - base_ : 0u);                                            \
+        /* round 2: which of the node's 16 symbols */                                                      \
+        U4* lg_ = leaves + node_ * 4 + j;                                                                  \
+        const U4 l_ = *lg_;                                                                                \
+        const u32 t2_ = l_.x + l_.y, t3_ = t2_ + l_.z, t4_ = t3_ + l_.w;                                   \
+        const u32 ex_ = rcx_quad_excl_scan(t4_, m1, m2);                                                   \
+        const u32 d2_ = rem_ - rcx_mul24(ex_, t_);                                                         \
+        const u32 a2_ = rcx_mul24(l_.x, t_), b2_ = rcx_mul24(t2_, t_), c2_ = rcx_mul24(t3_, t_);           \
+        const u32 e2_ = rcx_mul24(t4_, t_);                                                                \
+        u32 p2_ = 0, base2_ = 0, hit_ = l_.x;                                                              \
+        if (d2_ >= a2_) { p2_ = 1; base2_ = a2_; hit_ = l_.y; }                                            \
+        if (d2_ >= b2_) { p2_ = 2; base2_ = b2_; hit_ = l_.z; }                                            \
+        if (d2_ >= c2_) { p2_ = 3; base2_ = c2_; hit_ = l_.w; }                                            \
+        const bool own2_ = d2_ < e2_;                                                                      \
+        u32 low_ = rcx_quad_sum(own2_ ? d2_ - base2_ : 0u);                                                \
+        const u32 range_ = rcx_quad_sum(own2_ ? rcx_mul24(hit_, t_) : 0u);                                 \
+        const u32 lp_ = rcx_quad_sum(own2_ ? 4u * j + p2_ : 0u);                                           \
+        /* target >= total: the reference's find() falls through to code 0 / count = total */              \
+        if (dec.low >= top_) low_ = dec.low - top_;                                                        \
+        dec.low = low_;                                                                                    \
+        dec.range = range_;                                                                                \
+        /* cpprcoder.h:1134-1177, +1 on the symbol and on its node */                                      \
+        rcx_lds_add(reinterpret_cast<u32*>(lg_) + p2_, own2_ ? 1u : 0u);                                   \
+        const u32 grp_ = node_ >> 2;                                                                       \
+        rcx_lds_add(reinterpret_cast<u32*>(nodes) + (node_ & 3u), j == grp_ ? 1u : 0u);                    \
+        before += j > grp_ ? 1u : 0u;                                                                      \
+        (SYM) = node_ * 16 + lp_;                                                                          \
+    }
+
+    DivEntry ahead = divtab[lane];
+    if (full) {
+        for (u32 i0 = 0; i0 < maxlen; i0 += RCX_STAGE) {
+            stage[lane] = ahead;
+            ahead = divtab[i0 + RCX_STAGE + lane];
+            const u32 jend = (maxlen - i0) < RCX_STAGE ? (maxlen - i0) : RCX_STAGE;
+            for (u32 j0 = 0; j0 < jend; j0 += 16) {
+                const u32 i = i0 + j0;
+                u32 word[4] = {0, 0, 0, 0};
+                dec.topup();
+                DivEntry k_next = stage[j0];
+#pragma unroll
+                for (u32 s = 0; s < 16; ++s) {
+                    u32 sym;
+                    const DivEntry kk = k_next;
+                    if (s + 1 < 16) k_next = stage[j0 + s + 1];
+                    RCX_QUAD_DEC_SYMBOL(kk, sym);
+                    word[s >> 2] |= sym << (8 * (s & 3));
+                }
+                if (leader) {
+                    U4 o;
+                    o.x = word[0];
+                    o.y = word[1];
+                    o.z = word[2];
+                    o.w = word[3];
+                    *reinterpret_cast<U4*>(out + i) = o;
+                }
+            }
+        }
+    } else {
+        for (u32 i0 = 0; i0 < maxlen; i0 += RCX_STAGE) {
+            stage[lane] = ahead;
+            ahead = divtab[i0 + RCX_STAGE + lane];
+            const u32 jend = (maxlen - i0) < RCX_STAGE ? (maxlen - i0) : RCX_STAGE;
+            for (u32 s = 0; s < jend; ++s) {
+                const u32 i = i0 + s;
+                const DivEntry k = stage[s];
+                if ((s & 15u) == 0) dec.topup();
+                if (i < len) {
+                    u32 sym;
+                    RCX_QUAD_DEC_SYMBOL(k, sym);
+                    if (leader) out[i] = (u8)sym;
+                }
+            }
+        }
+    }
+#undef RCX_QUAD_DEC_SYMBOL
+    if (leader && dec.taken() > stream_len) rcx_flag(status, RCX_ST_CORRUPT, blk);
+}
