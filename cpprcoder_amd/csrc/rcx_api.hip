@@ -246,7 +246,7 @@ int rcx_encode_blocks_device(rcx_ctx* c, int coder, const void* d_src, uint64_t 
                              void* d_dst, uint64_t dst_cap, uint64_t* d_offsets, void* stream)
 {
     if (!c || !block_ok(block) || !d_offsets || (n && (!d_src || !d_dst))) return RCX_E_ARG;
-    if (coder != RCX_CODER_ADAPTIVE) return RCX_E_ARG;
+    if (coder != RCX_CODER_ADAPTIVE && coder != RCX_CODER_STATIC) return RCX_E_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(c->device));
     const u64 nblocks = rcx_block_count(n, block);
@@ -257,7 +257,11 @@ int rcx_encode_blocks_device(rcx_ctx* c, int coder, const void* d_src, uint64_t 
     const u64 slot = rcx_block_bound(block);
     {
         Timed t(c, s, RCX_T_ENCODE);
-        if (c->enc_variant == 2) {
+        if (coder == RCX_CODER_STATIC) {
+            const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
+            hipLaunchKernelGGL(rcx_enc_static_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block, nblocks,
+                               c->slots, slot, c->sizes, c->status);
+        } else if (c->enc_variant == 2) {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_enc_mc_k, dim3(grid), dim3(RCX_MC_THREADS), 0, s, static_cast<const u8*>(d_src), n, block, nblocks,
                                c->slots, slot, c->sizes, c->divtab, c->status);
@@ -289,7 +293,7 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
 {
     (void)comp_size;
     if (!c || !block_ok(block) || (nblocks && (!d_comp || !d_offsets || !d_dst))) return RCX_E_ARG;
-    if (coder != RCX_CODER_ADAPTIVE) return RCX_E_ARG;
+    if (coder != RCX_CODER_ADAPTIVE && coder != RCX_CODER_STATIC) return RCX_E_ARG;
     if (nblocks != rcx_block_count(n, block)) return RCX_E_ARG;
     if (nblocks == 0) return RCX_OK;
     if (nblocks > 0x7FFFFFFFull) return RCX_E_ARG;
@@ -299,7 +303,11 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
     if (r != RCX_OK) return r;
     {
         Timed t(c, s, RCX_T_DECODE);
-        if (c->lanes_per_block == 4) {
+        if (coder == RCX_CODER_STATIC) {
+            const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
+            hipLaunchKernelGGL(rcx_dec_static_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
+                               block, n, static_cast<u8*>(d_dst), c->status);
+        } else if (c->lanes_per_block == 4) {
             const u32 grid = (u32)((nblocks + RCX_QUAD_BLOCKS - 1) / RCX_QUAD_BLOCKS);
             hipLaunchKernelGGL(rcx_dec_quad_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
                                block, n, static_cast<u8*>(d_dst), c->divtab, c->status);

@@ -1,4 +1,5 @@
-// rcx_divtab.hpp -- host-side construction of the divisor table.
+// rcx_divtab.hpp -- construction of divisor-table entries (host: the adaptive coder's table;
+// device: the static coder's one divisor per block).
 //
 // Entry i serves total = 256 + i: the i-th symbol of a block sees exactly that total
 // (cpprcoder.h:1096 init to 256, :1138 +1 per symbol) as long as no halving happens,
@@ -11,7 +12,7 @@
 // (N-bit multiply-add division, Robison 2005: with k = 32 + floor(log2 d) either the
 //  rounded-up reciprocal fits 32 bits and is exact, or the rounded-down one applied
 //  to n+1 is).
-inline DivEntry rcx_make_div_entry(u32 d)
+RCX_HD DivEntry rcx_make_div_entry(u32 d)
 {
     DivEntry e;
     e.total = d;
@@ -22,9 +23,9 @@ inline DivEntry rcx_make_div_entry(u32 d)
         e.add = 0xFFFFFFFFu;
         return e;
     }
-    const unsigned __int128 pow = (unsigned __int128)1 << (32 + s);
-    const u64 down = (u64)(pow / d);
-    const u64 rem = (u64)(pow - (unsigned __int128)down * d);
+    const u64 pow = (u64)1 << (32 + s); // d is not a power of two, so s <= 30 and this fits
+    const u64 down = pow / d;
+    const u64 rem = pow - down * d;
     if ((u64)d - rem <= ((u64)1 << s)) { // round-up magic fits and is exact
         e.mul = (u32)(down + 1);
         e.add = 0;

@@ -298,3 +298,4 @@ __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ 
 }
 
 #include "rcx_oct.hpp"
+#include "rcx_static.hpp"

@@ -20,7 +20,9 @@
 
 #if defined(__HIPCC__)
 #define RCX_DEV __device__ __forceinline__
+#define RCX_HD __host__ __device__ inline
 #else
+#define RCX_HD inline
 #define RCX_DEV inline
 #define RCX_HOST_SIM 1
 #endif
@@ -260,13 +262,14 @@ struct EncLane {
 
     // One symbol with the model's answer already in hand: cum = sum of the counts below the
     // symbol, f = its count (cpprcoder.h:703-711).
-    template <bool TRACK = false>
+    // WIDE: full 32-bit multiplies (the static coder's total can be tiny, so t can exceed 24 bits).
+    template <bool TRACK = false, bool WIDE = false>
     RCX_DEV void code(u32 cum, u32 f, const DivEntry& k, u32 index = 0)
     {
         const u32 t = rcx_div(range, k);             // cpprcoder.h:703
-        const u32 moved = low + rcx_mul24(cum, t);   // :706  (cum*t <= range < 2^32, both factors < 2^24)
+        const u32 moved = low + (WIDE ? cum * t : rcx_mul24(cum, t)); // :706  (cum*t <= range < 2^32)
         const u32 carry = moved < low ? 1u : 0u;
-        range = rcx_mul24(f, t);                     // :707
+        range = WIDE ? f * t : rcx_mul24(f, t);      // :707
         acc += carry;                                // :767-781, resolved lazily (see flush)
 
         // :783-800 renormalise: k8/8 bytes leave through the top of low

@@ -26,7 +26,7 @@ def ctx():
     c.close()
 
 
-def gpu_encode(ctx, data, block, src_offset=0):
+def gpu_encode(ctx, data, block, src_offset=0, coder=0):
     """-> (payload np.uint8, offsets np.uint64) through the device-pointer entry points."""
     from cpprcoder_amd import rcx
     data = np.ascontiguousarray(data, dtype=np.uint8)
@@ -37,18 +37,18 @@ def gpu_encode(ctx, data, block, src_offset=0):
     nblocks = rcx.block_count(n, block)
     dst = torch.zeros(rcx.encode_bound(n, block), dtype=torch.uint8, device="cuda")
     offs = torch.zeros(nblocks + 1, dtype=torch.int64, device="cuda")
-    ctx.encode_blocks_device(src, block, dst, offs)
+    ctx.encode_blocks_device(src, block, dst, offs, coder=coder)
     ctx.sync_status()
     offsets = offs.cpu().numpy().astype(np.uint64)
     return dst[: int(offsets[-1])].cpu().numpy(), offsets, (dst, offs)
 
 
-def gpu_decode(ctx, payload, offsets, n, block, dst_offset=0, comp_offset=0):
+def gpu_decode(ctx, payload, offsets, n, block, dst_offset=0, comp_offset=0, coder=0):
     comp = torch.zeros(len(payload) + comp_offset + 16, dtype=torch.uint8, device="cuda")
     comp[comp_offset:comp_offset + len(payload)] = torch.from_numpy(np.ascontiguousarray(payload)).cuda()
     offs = torch.from_numpy(np.asarray(offsets).astype(np.int64)).cuda()
     out = torch.zeros(n + dst_offset + 16, dtype=torch.uint8, device="cuda")
-    ctx.decode_blocks_device(comp[comp_offset:], len(payload), offs, n, block, out[dst_offset:])
+    ctx.decode_blocks_device(comp[comp_offset:], len(payload), offs, n, block, out[dst_offset:], coder=coder)
     st, bad = ctx.sync_status(raise_on_error=False)
     return out[dst_offset:dst_offset + n].cpu().numpy(), st, bad
 
@@ -62,16 +62,15 @@ def assert_same_blocks(payload, offsets, slots, sizes):
 
 def test_golden_block_tables(ctx, golden):
     for t in golden["blocks"]:
-        if t["coder"] != "adaptive":
-            continue
+        coder = 0 if t["coder"] == "adaptive" else 1
         data = workloads.by_name(t["workload"], t["n"], t["seed"])
         assert hashlib.sha256(data.tobytes()).hexdigest() == t["input_sha256"]
-        payload, offsets, _ = gpu_encode(ctx, data, t["block"])
+        payload, offsets, _ = gpu_encode(ctx, data, t["block"], coder=coder)
         assert [int(x) for x in np.diff(offsets.astype(np.int64))] == t["sizes"], (t["workload"], t["block"])
         fnv = ["%016x" % oracle_lib.fnv1a64(payload[int(offsets[b]): int(offsets[b + 1])]) for b in range(len(t["sizes"]))]
         assert fnv == t["fnv1a64"], (t["workload"], t["block"])
         assert int(offsets[-1]) == t["total"]
-        back, st, _ = gpu_decode(ctx, payload, offsets, t["n"], t["block"])
+        back, st, _ = gpu_decode(ctx, payload, offsets, t["n"], t["block"], coder=coder)
         assert st == 0 and np.array_equal(back, data)
 
 
@@ -251,3 +250,67 @@ def test_full_size_properties(ctx, oracle):
         (st, _), ref, size = oracle.adaptive_encode(blk)
         got = dst[int(offsets[b]): int(offsets[b + 1])].cpu().numpy().tobytes()
         assert st == 0 and got == ref, f"block {b}"
+
+
+# ---------------------------------------------------------------------------
+# Static (two-pass) coder, RangeEncoder<T> (cpprcoder.h:321-619)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("block", [16, 100, 4096, 65536, 65552, 262144])
+def test_static_ragged_sizes_match_oracle(ctx, oracle, block):
+    rs = np.random.RandomState(block + 1)
+    for trial in range(3):
+        nblocks = int(rs.randint(1, 150 if block <= 4096 else (70 if block <= 65552 else 5)))
+        n = block * (nblocks - 1) + int(rs.randint(1, block + 1))
+        wl = ("uniform", "zipf", "runs", "canterbury")[trial % 4] if trial else "canterbury"
+        data = workloads.by_name(wl, n, 2000 + trial)
+        slots, sizes = oracle.encode_blocks(data, block, coder=1, threads=8)
+        off = (0, 1, 5)[trial]
+        payload, offsets, _ = gpu_encode(ctx, data, block, src_offset=off, coder=1)
+        assert_same_blocks(payload, offsets, slots, sizes)
+        back, st, _ = gpu_decode(ctx, payload, offsets, n, block, dst_offset=off, comp_offset=(0, 3, 2)[trial], coder=1)
+        assert st == 0 and np.array_equal(back, data)
+
+
+def test_static_edge_inputs(ctx, oracle, golden):
+    files = workloads.canterbury_files()
+    cases = [
+        (np.full(65535, 65, np.uint8), 65536), (np.full(65536, 65, np.uint8), 65536),   # the 16-bit squeeze (cpprcoder.h:549-555)
+        (np.full(65537 + 65536, 65, np.uint8), 1 << 20), (np.full(1 << 20, 200, np.uint8), 1 << 20),
+        (np.concatenate([np.full(70000, 1, np.uint8), workloads.zipf(200000, 3), np.full(140000, 1, np.uint8)]), 1 << 20),
+        (np.arange(256, dtype=np.uint8).repeat(3), 768), (np.array([7], np.uint8), 65536), (np.array([0, 255], np.uint8), 16),
+        (np.frombuffer(files["ptt5"], np.uint8), 1 << 20), (np.frombuffer(files["kennedy.xls"], np.uint8), 1 << 20),
+        (np.frombuffer(files["alice29.txt"], np.uint8), 1 << 20),
+    ]
+    for data, block in cases:
+        slots, sizes = oracle.encode_blocks(data, block, coder=1, threads=8)
+        payload, offsets, _ = gpu_encode(ctx, data, block, coder=1)
+        assert_same_blocks(payload, offsets, slots, sizes)
+        back, st, _ = gpu_decode(ctx, payload, offsets, len(data), block, coder=1)
+        assert st == 0 and np.array_equal(back, data)
+    # README.md:20-30: the published static sizes, each file as one block
+    for name in workloads.CANTERBURY_ORDER:
+        data = np.frombuffer(files[name], np.uint8)
+        payload, offsets, _ = gpu_encode(ctx, data, 1 << 20, coder=1)
+        assert len(payload) == golden["kat"]["canterbury"][name]["static_size"]
+        assert hashlib.sha256(payload.tobytes()).hexdigest() == golden["kat"]["canterbury"][name]["static_sha256"]
+
+
+def test_static_corrupt_streams(ctx, oracle):
+    from cpprcoder_amd import rcx
+    data = workloads.zipf(65536 * 3 + 500, 8)
+    payload, offsets, _ = gpu_encode(ctx, data, 65536, coder=1)
+    cut = offsets.copy()
+    cut[-1] -= 30  # truncated last block
+    _, st, blk = gpu_decode(ctx, payload[: int(cut[-1])], cut, len(data), 65536, coder=1)
+    assert st == rcx.E_CORRUPT and blk == 3
+    bad = payload.copy()
+    bad[int(offsets[1]) + 4: int(offsets[1]) + 516] = 0  # block 1: all counts zero -> total 0
+    _, st, blk = gpu_decode(ctx, bad, offsets, len(data), 65536, coder=1)
+    assert st == rcx.E_CORRUPT and blk == 1
+    back, st, _ = gpu_decode(ctx, payload, offsets, len(data), 65536, coder=1)
+    assert st == 0 and np.array_equal(back, data)
+    # streams made by the CPU coder decode on the GPU
+    slots, sizes = oracle.encode_blocks(data, 65536, coder=1, threads=8)
+    p2, o2 = oracle.compact(slots, sizes)
+    back, st, _ = gpu_decode(ctx, p2, o2, len(data), 65536, coder=1)
+    assert st == 0 and np.array_equal(back, data)
