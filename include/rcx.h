@@ -53,7 +53,8 @@ enum {
     RCX_E_NOMEM = -6     /* device or host allocation failed */
 };
 
-/* Which coder a call uses. */
+/* Which coder a call uses.  The block entry points take either; the single-stream entry points
+ * (rcx_stream_*) take RCX_CODER_ADAPTIVE only. */
 enum {
     RCX_CODER_ADAPTIVE = 0, /* AdaptiveRangeEncoder/Decoder, cpprcoder.h:626-940 */
     RCX_CODER_STATIC = 1    /* RangeEncoder (two-pass, 516-byte table header), cpprcoder.h:321-619 */

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "sweep.jsonl"))
     ap.add_argument("--workloads", default="uniform,canterbury,zipf")
     ap.add_argument("--blocks", default="4096,8192,16384,32768,65536,131072,262144")
+    ap.add_argument("--coder", type=int, default=0, help="0 adaptive, 1 static")
     args = ap.parse_args()
     import torch
     from cpprcoder_amd import rcx, workloads
@@ -43,8 +44,8 @@ def main():
                 for rep in range(4):
                     ctx.set_timing(True)
                     ctx.get_timing(reset=True)
-                    ctx.encode_blocks_device(src, block, dst, offs)
-                    ctx.decode_blocks_device(dst, dst.numel(), offs, n, block, out)
+                    ctx.encode_blocks_device(src, block, dst, offs, coder=args.coder)
+                    ctx.decode_blocks_device(dst, dst.numel(), offs, n, block, out, coder=args.coder)
                     ctx.sync_status()
                     t = ctx.get_timing(reset=True)
                     if rep:
@@ -53,7 +54,7 @@ def main():
                 ok = bool(torch.equal(out, src))
                 total = int(offs[-1])
                 e, d = sorted(enc_ms)[1], sorted(dec_ms)[1]
-                line = {"workload": wl, "bytes": n, "block": block, "blocks": nblocks, "ratio": round(total / n, 6),
+                line = {"coder": ("adaptive", "static")[args.coder], "workload": wl, "bytes": n, "block": block, "blocks": nblocks, "ratio": round(total / n, 6),
                         "encode_ms": round(e, 3), "decode_ms": round(d, 3), "encode_MBps": round(n / 1e6 / (e * 1e-3), 1),
                         "decode_MBps": round(n / 1e6 / (d * 1e-3), 1), "roundtrip_MBps": round(n / 1e6 / ((e + d) * 1e-3), 1),
                         "roundtrip_ok": ok, "gen_s": round(gen_s, 1)}
