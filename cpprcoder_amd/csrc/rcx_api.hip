@@ -33,7 +33,7 @@ struct EventPair {
 
 struct rcx_ctx {
     int device = 0;
-    int lanes_per_block = 8; // decode: 8 = octet kernel (default, fastest measured), 4 = quad, 1 = one lane per block (RCX_LANES_PER_BLOCK)
+    int lanes_per_block = 0; // decode: 0 = pick by block count (default), 8 = octet, 4 = quad, 1 = one lane per block (RCX_LANES_PER_BLOCK)
     int enc_variant = 2;     // encode: 0 = one lane per block, 1 = octet, 2 = model/coder wave split (RCX_ENC_VARIANT)
     // scratch
     u8* slots = nullptr;
@@ -119,6 +119,17 @@ int ensure_divtab(rcx_ctx* c, u32 block)
 
 bool block_ok(uint32_t block) { return block >= RCX_MIN_BLOCK && block <= RCX_MAX_BLOCK; }
 
+// Lanes per block for the adaptive decoder.  A wave-instruction costs its SIMD 4 cycles whatever it
+// serves, so fewer lanes per block means less machine-wide work, but a lone wave per SIMD exposes every
+// wait.  Measured on 1 GiB (profiles/): the quad kernel wins whenever it either gets >= 2 waves per SIMD
+// (>= 32768 blocks) or cannot fill the SIMDs anyway (<= 8192 blocks); around 16384 blocks -- where quad
+// is exactly one wave per SIMD and octet two -- the octet kernel wins.
+int decode_lanes(const rcx_ctx* c, u64 nblocks)
+{
+    if (c->lanes_per_block) return c->lanes_per_block;
+    return (nblocks > 12288 && nblocks < 24576) ? 8 : 4;
+}
+
 int reserve(rcx_ctx* c, u64 n, u32 block)
 {
     const u64 nblocks = rcx_block_count(n, block);
@@ -179,7 +190,7 @@ int rcx_ctx_create(int device, rcx_ctx** out)
     rcx_ctx* c = new (std::nothrow) rcx_ctx();
     if (!c) return RCX_E_NOMEM;
     c->device = device;
-    if (const char* v = getenv("RCX_LANES_PER_BLOCK")) c->lanes_per_block = (atoi(v) == 1 || atoi(v) == 4) ? atoi(v) : 8;
+    if (const char* v = getenv("RCX_LANES_PER_BLOCK")) c->lanes_per_block = (atoi(v) == 1 || atoi(v) == 4 || atoi(v) == 8) ? atoi(v) : 0;
     if (const char* v = getenv("RCX_ENC_VARIANT")) c->enc_variant = atoi(v) >= 0 && atoi(v) <= 2 ? atoi(v) : 2;
     if (hipMalloc(reinterpret_cast<void**>(&c->status), 4 * sizeof(u32)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&c->status_host), 4 * sizeof(u32), hipHostMallocDefault) != hipSuccess) {
@@ -307,11 +318,11 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_dec_static_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
                                block, n, static_cast<u8*>(d_dst), c->status);
-        } else if (c->lanes_per_block == 4) {
+        } else if (decode_lanes(c, nblocks) == 4) {
             const u32 grid = (u32)((nblocks + RCX_QUAD_BLOCKS - 1) / RCX_QUAD_BLOCKS);
             hipLaunchKernelGGL(rcx_dec_quad_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
                                block, n, static_cast<u8*>(d_dst), c->divtab, c->status);
-        } else if (c->lanes_per_block == 8) {
+        } else if (decode_lanes(c, nblocks) == 8) {
             const u32 grid = (u32)((nblocks + RCX_OCT_BLOCKS - 1) / RCX_OCT_BLOCKS);
             hipLaunchKernelGGL(rcx_dec_oct_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
                                block, n, static_cast<u8*>(d_dst), c->divtab, c->status);

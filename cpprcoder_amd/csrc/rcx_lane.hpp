@@ -97,11 +97,7 @@ RCX_DEV u32 rcx_funnel_shr(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_ali
 #define RCX_COLD __device__ __attribute__((noinline, cold))
 #endif
 
-#if defined(RCX_ABLATE_DIV) /* timing experiments only */
-RCX_DEV u32 rcx_div(u32 n, const DivEntry& k) { return (n >> 9) + (k.mul & 1) + (k.add & 1) + (k.shift & 1); }
-#else
 RCX_DEV u32 rcx_div(u32 n, const DivEntry& k) { return (u32)(((u64)n * k.mul + k.add) >> 32) >> k.shift; }
-#endif
 
 // The tree of one lane.  `base` already includes the lane offset.
 struct Tree {
@@ -275,22 +271,12 @@ struct EncLane {
         // :783-800 renormalise: k8/8 bytes leave through the top of low
         const u32 k8 = rcx_clz(range) & 0x18u;
         if (TRACK) track(index, carry, moved, k8);
-#if defined(RCX_ABLATE_EMIT) /* timing experiments only */
-        const u64 shifted = (u64)moved << k8;
-        low = (u32)shifted;
-        acc ^= moved;
-#else
         const u64 shifted = (u64)moved << k8;
         low = (u32)shifted;
         acc = (acc << k8) | (shifted >> 32);
-#endif
         range <<= k8;
         nacc8 += k8;
-#if !defined(RCX_ABLATE_FLUSH)
         flush();
-#else
-        nacc8 &= 31u;
-#endif
     }
 
     // With 5..7 bytes held: store the 4 oldest, keep 1..3.  Some lane of a wave is in that state on
@@ -307,13 +293,7 @@ struct EncLane {
         const u32 extra = due ? acc_hi >> keep8 : 0u;            // a carry that ran off the held bytes
         if (rcx_any(extra != 0)) rcx_carry_slow(base + off, leader ? (pos < cap ? pos : 0u) : 0u, extra);
         const u32 where = pos < cap - 4 ? pos : cap - 4;
-        if (due && leader) {
-#if !defined(RCX_ABLATE_STORE) /* timing experiments only: never defined in a shipped build */
-            *reinterpret_cast<u32*>(base + (off + where)) = rcx_bswap(word);
-#else
-            asm volatile("" ::"v"(word), "v"(where));
-#endif
-        }
+        if (due && leader) *reinterpret_cast<u32*>(base + (off + where)) = rcx_bswap(word);
         const u32 kept = acc_lo & ((1u << keep8) - 1u);
         acc = due ? (u64)kept : acc;
         nacc8 -= due ? 32u : 0u;
@@ -405,12 +385,7 @@ struct DecLane {
     {
         U4 z;
         z.x = z.y = z.z = z.w = 0;
-#if defined(RCX_ABLATE_DLOAD) /* timing experiments only */
-        z.x = (u32)(uintptr_t)p;
-        return z;
-#else
         return p < end ? *reinterpret_cast<const U4*>(p) : z;
-#endif
     }
     RCX_DEV void ring_put(const U4& piece)
     {
@@ -565,12 +540,7 @@ struct DecLane {
         low = rem;                // :906
         range = rcx_mul24(f, t);  // :907
         // :916 +1 on the path to the leaf (after the last symbol the table is never looked at again)
-#if defined(RCX_ABLATE_DUPDATE) /* timing experiments only */
-        asm volatile("" ::"v"(hit3), "v"(hit2), "v"(hit1), "v"(c3), "v"(c2), "v"(c1), "v"(off_table));
-        if (false) {
-#else
         if (off_table) {
-#endif
             tree.update(0);
         } else {
             tree.put(RCX_G_L3, c3, hit3 + 1);

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("RCX_LIBRARY") or os.path.join(HERE, "librcx.so")  # RCX_LIBRARY: timing experiments only
+LIB_PATH = os.environ.get("RCX_LIBRARY") or os.path.join(HERE, "librcx.so")  # RCX_LIBRARY: a diagnostic (stamped) build
 
 OK, PENDING, ERROR, E_ARG, E_CAPACITY, E_CORRUPT, E_HIP, E_NOMEM = 0, 1, -1, -2, -3, -4, -5, -6
 CODER_ADAPTIVE, CODER_STATIC = 0, 1

@@ -314,3 +314,31 @@ def test_static_corrupt_streams(ctx, oracle):
     p2, o2 = oracle.compact(slots, sizes)
     back, st, _ = gpu_decode(ctx, p2, o2, len(data), 65536, coder=1)
     assert st == 0 and np.array_equal(back, data)
+
+
+def test_every_kernel_variant_is_bit_identical(oracle):
+    """The selectable encode kernels (one wave / 8 lanes per block / model-coder wave split) and decode
+    kernels (1, 4, 8 lanes per block) must all produce the oracle's bytes; the default picks by block count."""
+    import os
+    from cpprcoder_amd import rcx
+    data = workloads.canterbury_tiled(65536 * 37 + 4321)
+    saved = {k: os.environ.get(k) for k in ("RCX_ENC_VARIANT", "RCX_LANES_PER_BLOCK")}
+    try:
+        for block in (4096, 65536):
+            slots, sizes = oracle.encode_blocks(data, block, threads=8)
+            ref_payload, ref_offsets = oracle.compact(slots, sizes)
+            for enc in ("0", "1", "2"):
+                for dec in ("1", "4", "8"):
+                    os.environ["RCX_ENC_VARIANT"], os.environ["RCX_LANES_PER_BLOCK"] = enc, dec
+                    c = rcx.Context(0)
+                    payload, offsets, _ = gpu_encode(c, data, block)
+                    assert np.array_equal(payload, ref_payload) and np.array_equal(offsets, ref_offsets), (block, enc)
+                    back, st, _ = gpu_decode(c, payload, offsets, len(data), block)
+                    assert st == 0 and np.array_equal(back, data), (block, dec)
+                    c.close()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
