@@ -198,7 +198,7 @@ def main() -> None:
         scat_ms = timing["scatter"]["ms"] / max(1, timing["scatter"]["launches"])
         auto = "rcx_dec_oct_k" if 12288 < nblocks < 24576 else "rcx_dec_quad_k"  # rcx_api.hip: decode_lanes()
         dec_name = {"1": "rcx_dec_adaptive_k", "4": "rcx_dec_quad_k", "8": "rcx_dec_oct_k"}.get(os.environ.get("RCX_LANES_PER_BLOCK", ""), auto)
-        enc_name = {"0": "rcx_enc_adaptive_k", "1": "rcx_enc_oct_k"}.get(os.environ.get("RCX_ENC_VARIANT", ""), "rcx_enc_mc_k")
+        enc_name = {"0": "rcx_enc_adaptive_k", "1": "rcx_enc_oct_k", "2": "rcx_enc_mc_k"}.get(os.environ.get("RCX_ENC_VARIANT", ""), "rcx_enc_mc5_k")
         dom, dom_ms = (dec_name, dec_ms) if dec_ms >= enc_ms else (enc_name, enc_ms)
         algo_bytes = (1.0 + ratio) * n  # 1 read + r write per input byte (or r read + 1 write)
         achieved = algo_bytes / (dom_ms * 1e-3) / 1e9

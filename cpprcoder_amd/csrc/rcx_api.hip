@@ -34,7 +34,7 @@ struct EventPair {
 struct rcx_ctx {
     int device = 0;
     int lanes_per_block = 0; // decode: 0 = pick by block count (default), 8 = octet, 4 = quad, 1 = one lane per block (RCX_LANES_PER_BLOCK)
-    int enc_variant = 2;     // encode: 0 = one lane per block, 1 = octet, 2 = model/coder wave split (RCX_ENC_VARIANT)
+    int enc_variant = 3;     // encode: 0 = one wave per 64 blocks, 1 = octet, 2 = 4-wave model/coder split, 3 = 5-wave split (RCX_ENC_VARIANT)
     // scratch
     u8* slots = nullptr;
     u64 slots_bytes = 0;
@@ -191,7 +191,7 @@ int rcx_ctx_create(int device, rcx_ctx** out)
     if (!c) return RCX_E_NOMEM;
     c->device = device;
     if (const char* v = getenv("RCX_LANES_PER_BLOCK")) c->lanes_per_block = (atoi(v) == 1 || atoi(v) == 4 || atoi(v) == 8) ? atoi(v) : 0;
-    if (const char* v = getenv("RCX_ENC_VARIANT")) c->enc_variant = atoi(v) >= 0 && atoi(v) <= 2 ? atoi(v) : 2;
+    if (const char* v = getenv("RCX_ENC_VARIANT")) c->enc_variant = atoi(v) >= 0 && atoi(v) <= 3 ? atoi(v) : 3;
     if (hipMalloc(reinterpret_cast<void**>(&c->status), 4 * sizeof(u32)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&c->status_host), 4 * sizeof(u32), hipHostMallocDefault) != hipSuccess) {
         rcx_ctx_destroy(c);
@@ -272,6 +272,10 @@ int rcx_encode_blocks_device(rcx_ctx* c, int coder, const void* d_src, uint64_t 
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_enc_static_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block, nblocks,
                                c->slots, slot, c->sizes, c->status);
+        } else if (c->enc_variant == 3) {
+            const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
+            hipLaunchKernelGGL(rcx_enc_mc5_k, dim3(grid), dim3(RCX_MC5_THREADS), 0, s, static_cast<const u8*>(d_src), n, block,
+                               nblocks, c->slots, slot, c->sizes, c->divtab, c->status);
         } else if (c->enc_variant == 2) {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_enc_mc_k, dim3(grid), dim3(RCX_MC_THREADS), 0, s, static_cast<const u8*>(d_src), n, block, nblocks,

@@ -257,26 +257,37 @@ struct EncLane {
     RCX_DEV bool track_flush_fails() const { return trk_written + 1 + trk_pending > trk_cap; }
 
     // One symbol with the model's answer already in hand: cum = sum of the counts below the
-    // symbol, f = its count (cpprcoder.h:703-711).
+    // symbol, f = its count (cpprcoder.h:703-711).  Two halves so that they can also run in two
+    // different waves: arith() is the interval arithmetic (state: low, range) and returns a
+    // record {top 24 bits of the moved low | bytes leaving << 1 | carry}; emit() is the byte
+    // writer (state: acc, nacc8, pos).
     // WIDE: full 32-bit multiplies (the static coder's total can be tiny, so t can exceed 24 bits).
-    template <bool TRACK = false, bool WIDE = false>
-    RCX_DEV void code(u32 cum, u32 f, const DivEntry& k, u32 index = 0)
+    template <bool WIDE = false>
+    RCX_DEV u32 arith(u32 cum, u32 f, const DivEntry& k)
     {
         const u32 t = rcx_div(range, k);             // cpprcoder.h:703
         const u32 moved = low + (WIDE ? cum * t : rcx_mul24(cum, t)); // :706  (cum*t <= range < 2^32)
         const u32 carry = moved < low ? 1u : 0u;
         range = WIDE ? f * t : rcx_mul24(f, t);      // :707
-        acc += carry;                                // :767-781, resolved lazily (see flush)
-
-        // :783-800 renormalise: k8/8 bytes leave through the top of low
-        const u32 k8 = rcx_clz(range) & 0x18u;
-        if (TRACK) track(index, carry, moved, k8);
-        const u64 shifted = (u64)moved << k8;
-        low = (u32)shifted;
-        acc = (acc << k8) | (shifted >> 32);
+        const u32 k8 = rcx_clz(range) & 0x18u;       // :783-800: k8/8 bytes leave through the top of low
+        low = moved << k8;
         range <<= k8;
+        return (moved & 0xFFFFFF00u) | (k8 >> 2) | carry;
+    }
+    RCX_DEV void emit(u32 rec)
+    {
+        const u32 k8 = (rec << 2) & 0x18u;
+        acc += rec & 1u;                             // :767-781 carry, resolved lazily (see flush)
+        acc = (acc << k8) | (((u64)rec << k8) >> 32);
         nacc8 += k8;
         flush();
+    }
+    template <bool TRACK = false, bool WIDE = false>
+    RCX_DEV void code(u32 cum, u32 f, const DivEntry& k, u32 index = 0)
+    {
+        const u32 rec = arith<WIDE>(cum, f, k);
+        if (TRACK) track(index, rec & 1u, rec & 0xFFFFFF00u, (rec << 2) & 0x18u);
+        emit(rec);
     }
 
     // With 5..7 bytes held: store the 4 oldest, keep 1..3.  Some lane of a wave is in that state on

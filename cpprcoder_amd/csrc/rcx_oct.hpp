@@ -718,3 +718,227 @@ __global__ __launch_bounds__(64) void rcx_dec_quad_k(const u8* __restrict__ comp
 #undef RCX_QUAD_DEC_SYMBOL
     if (leader && dec.taken() > stream_len) rcx_flag(status, RCX_ST_CORRUPT, blk);
 }
+
+// ===========================================================================
+// Encode, pass 1, five-wave split ("MC5"): as rcx_enc_mc_k, with the coder itself cut in two
+// (EncLane::arith / EncLane::emit): the interval arithmetic (state low, range) and the byte
+// writer (state acc / nacc8 / pos, the global stores) are separate waves connected by a second
+// LDS ring of one record per symbol.  Three pipeline stages, one chunk apart:
+//   waves M1..M3 (model, chunk k) -> wave A (arithmetic, chunk k-1) -> wave W (writer, chunk k-2)
+// Five waves on four SIMDs: the two lightest (A and the level-1 model wave) are meant to share one.
+// ===========================================================================
+#define RCX_MC5_THREADS 320
+#define RCX_MC5_RING2_DW (2 * RCX_MC_CHUNK * RCX_LANES)
+#define RCX_MC5_LDS_U4 (RCX_MC_LDS_U4 + RCX_MC5_RING2_DW / 4 + RCX_LANES / 4)
+
+template <bool FULL>
+__device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u32 nchunks, const u8* in,
+                                                 const DivEntry* __restrict__ divtab, const Tree& tree, DivEntry* stage,
+                                                 U4* ring, u32* ring2, EncLane& enc, DivEntry& ahead)
+{
+    // wave roles: 0 arithmetic, 1 writer, 2 model levels 3+2, 3 model leaf level, 4 model level 1
+#if defined(RCX_STAMP)
+    unsigned long long stamp_wait_ = 0;
+    const unsigned long long stamp_begin_ = __builtin_amdgcn_s_memtime();
+#endif
+    U4 piece_ahead;
+    piece_ahead.x = piece_ahead.y = piece_ahead.z = piece_ahead.w = 0;
+    if (FULL && wave >= 2 && nchunks > 0) piece_ahead = *reinterpret_cast<const U4*>(in);
+    for (u32 k = 0; k <= nchunks + 1; ++k) {
+        if (wave == 0) {
+            // ---- arithmetic: chunk k-1, records into ring2[(k-1)&1] ----
+            if (k >= 1 && k <= nchunks) {
+                const u32 i0 = (k - 1) * RCX_MC_CHUNK;
+                if ((i0 % RCX_STAGE) == 0) {
+                    stage[lane] = ahead;
+                    ahead = divtab[i0 + RCX_STAGE + lane];
+                }
+                const U4* rs = ring + ((k - 1) & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
+                u32* ws2 = ring2 + ((k - 1) & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
+                const DivEntry* st = stage + (i0 % RCX_STAGE);
+                U4 e_next = rs[0];
+                DivEntry k_next = st[0];
+#pragma unroll
+                for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
+                    const U4 e = e_next;
+                    const DivEntry kk = k_next;
+                    if (s + 1 < RCX_MC_CHUNK) {
+                        e_next = rs[(s + 1) * RCX_LANES];
+                        k_next = st[s + 1];
+                    }
+                    u32 rec = 0; // past the end of a short block: a record that does nothing
+                    if (FULL || i0 + s < len) rec = enc.arith(e.x + e.y + e.z, e.w, kk);
+                    ws2[s * RCX_LANES] = rec;
+                }
+            }
+        } else if (wave == 1) {
+            // ---- writer: chunk k-2 from ring2[(k-2)&1] ----
+            if (k >= 2) {
+                const u32* rs2 = ring2 + ((k - 2) & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
+                u32 r_next = rs2[0];
+#pragma unroll
+                for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
+                    const u32 rec = r_next;
+                    if (s + 1 < RCX_MC_CHUNK) r_next = rs2[(s + 1) * RCX_LANES];
+                    enc.emit(rec);
+                }
+            }
+        } else if (k < nchunks) {
+            // ---- model: chunk k ----
+            const u32 i0 = k * RCX_MC_CHUNK;
+            U4* ws = ring + (k & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
+            U4 piece;
+            if (FULL) {
+                piece = piece_ahead;
+                if (k + 1 < nchunks) piece_ahead = *reinterpret_cast<const U4*>(in + i0 + RCX_MC_CHUNK);
+            } else {
+                u32 w[4] = {0, 0, 0, 0};
+                for (u32 s = 0; s < RCX_MC_CHUNK; ++s)
+                    if (i0 + s < len) w[s >> 2] |= (u32)in[i0 + s] << (8 * (s & 3));
+                piece.x = w[0];
+                piece.y = w[1];
+                piece.z = w[2];
+                piece.w = w[3];
+            }
+            if (wave == 2) {
+                u32 c = rcx_byte_of(piece, 0);
+                bool on = FULL || i0 < len;
+                U4 g3 = tree.group(RCX_G_L3), g2 = tree.group(RCX_G_L2 + (c >> 6));
+                if (on) {
+                    tree.bump(RCX_G_L3, c >> 6);
+                    tree.bump(RCX_G_L2 + (c >> 6), (c >> 4) & 3);
+                }
+#pragma unroll
+                for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
+                    const u32 cc = c;
+                    const bool onc = on;
+                    const U4 h3 = g3, h2 = g2;
+                    if (s + 1 < RCX_MC_CHUNK) {
+                        c = rcx_byte_of(piece, s + 1);
+                        on = FULL || i0 + s + 1 < len;
+                        g3 = tree.group(RCX_G_L3);
+                        g2 = tree.group(RCX_G_L2 + (c >> 6));
+                        if (on) {
+                            tree.bump(RCX_G_L3, c >> 6);
+                            tree.bump(RCX_G_L2 + (c >> 6), (c >> 4) & 3);
+                        }
+                    }
+                    if (onc) reinterpret_cast<u32*>(&ws[s * RCX_LANES])[0] = rcx_pre4(h3, cc >> 6) + rcx_pre4(h2, (cc >> 4) & 3);
+                }
+            } else if (wave == 4) {
+                u32 c = rcx_byte_of(piece, 0);
+                bool on = FULL || i0 < len;
+                U4 g1 = tree.group(RCX_G_L1 + (c >> 4));
+                if (on) tree.bump(RCX_G_L1 + (c >> 4), (c >> 2) & 3);
+#pragma unroll
+                for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
+                    const u32 cc = c;
+                    const bool onc = on;
+                    const U4 h1 = g1;
+                    if (s + 1 < RCX_MC_CHUNK) {
+                        c = rcx_byte_of(piece, s + 1);
+                        on = FULL || i0 + s + 1 < len;
+                        g1 = tree.group(RCX_G_L1 + (c >> 4));
+                        if (on) tree.bump(RCX_G_L1 + (c >> 4), (c >> 2) & 3);
+                    }
+                    if (onc) reinterpret_cast<u32*>(&ws[s * RCX_LANES])[1] = rcx_pre4(h1, (cc >> 2) & 3);
+                }
+            } else {
+                u32 c = rcx_byte_of(piece, 0);
+                bool on = FULL || i0 < len;
+                U4 g0 = tree.group(RCX_G_L0 + (c >> 2));
+                if (on) tree.bump(RCX_G_L0 + (c >> 2), c & 3);
+#pragma unroll
+                for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
+                    const u32 cc = c;
+                    const bool onc = on;
+                    const U4 h0 = g0;
+                    if (s + 1 < RCX_MC_CHUNK) {
+                        c = rcx_byte_of(piece, s + 1);
+                        on = FULL || i0 + s + 1 < len;
+                        g0 = tree.group(RCX_G_L0 + (c >> 2));
+                        if (on) tree.bump(RCX_G_L0 + (c >> 2), c & 3);
+                    }
+                    if (onc) {
+                        u32* e = reinterpret_cast<u32*>(&ws[s * RCX_LANES]);
+                        e[2] = rcx_pre4(h0, cc & 3);
+                        e[3] = rcx_sel4(h0, cc & 3);
+                    }
+                }
+            }
+        }
+#if defined(RCX_STAMP)
+        const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+        rcx_lds_barrier();
+        stamp_wait_ += __builtin_amdgcn_s_memtime() - t0_;
+#else
+        rcx_lds_barrier();
+#endif
+    }
+#if defined(RCX_STAMP)
+    if (blockIdx.x == 7 && lane == 0) {
+        rcx_stamp_out[wave * 2] = __builtin_amdgcn_s_memtime() - stamp_begin_;
+        rcx_stamp_out[wave * 2 + 1] = stamp_wait_;
+    }
+#endif
+}
+
+__global__ __launch_bounds__(RCX_MC5_THREADS) void rcx_enc_mc5_k(const u8* __restrict__ src, u64 n, u32 block, u64 nblocks,
+                                                                u8* __restrict__ slots, u64 slot, u32* __restrict__ sizes,
+                                                                const DivEntry* __restrict__ divtab, u32* status)
+{
+    __shared__ U4 lds[RCX_MC5_LDS_U4];
+    const u32 lane = threadIdx.x & 63u;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u64 blk = (u64)blockIdx.x * RCX_LANES + lane;
+    const bool live = blk < nblocks;
+    const u64 at = live ? blk * (u64)block : 0;
+    const u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
+
+    Tree tree{lds + lane};
+    DivEntry* stage = reinterpret_cast<DivEntry*>(lds + RCX_GROUPS * RCX_LANES);
+    U4* ring = lds + RCX_LDS_U4;
+    u32* ring2 = reinterpret_cast<u32*>(lds + RCX_MC_LDS_U4);
+    u32* final_low = ring2 + RCX_MC5_RING2_DW; // 64 dwords: the arithmetic wave's last low, for the writer's finish()
+
+    const u32 maxlen = rcx_wave_max(len);
+    const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+    const u8* in = src + at;
+    const u32 nchunks = (maxlen + RCX_MC_CHUNK - 1) / RCX_MC_CHUNK;
+
+    EncLane enc;
+    u8* wave_slots = slots + (u64)blockIdx.x * RCX_LANES * slot;
+    enc.idle(wave_slots); // waves 0 and 1 each use their half of the state
+    DivEntry ahead;
+    ahead.mul = ahead.add = ahead.shift = ahead.total = 0;
+    U4 v;
+    if (wave == 0) {
+        ahead = divtab[lane];
+    } else if (wave == 1) {
+        if (live) enc.begin(wave_slots, lane * (u32)slot, (u32)slot, len);
+    } else if (wave == 2) { // cpprcoder.h:1094-1132: every count 1
+        v.x = v.y = v.z = v.w = 64;
+        tree.base[0] = v;
+        v.x = v.y = v.z = v.w = 16;
+        for (u32 g = RCX_G_L2; g < RCX_G_L1; ++g) tree.base[g * RCX_LANES] = v;
+    } else if (wave == 4) {
+        v.x = v.y = v.z = v.w = 4;
+        for (u32 g = RCX_G_L1; g < RCX_G_L0; ++g) tree.base[g * RCX_LANES] = v;
+    } else {
+        v.x = v.y = v.z = v.w = 1;
+        for (u32 g = RCX_G_L0; g < RCX_GROUPS; ++g) tree.base[g * RCX_LANES] = v;
+    }
+    rcx_lds_barrier();
+
+    if (full) rcx_mc5_pipeline<true>(wave, lane, len, nchunks, in, divtab, tree, stage, ring, ring2, enc, ahead);
+    else rcx_mc5_pipeline<false>(wave, lane, len, nchunks, in, divtab, tree, stage, ring, ring2, enc, ahead);
+
+    if (wave == 0) final_low[lane] = enc.low;
+    rcx_lds_barrier();
+    if (wave == 1 && live) {
+        enc.low = final_low[lane];
+        const u32 bytes = enc.finish();
+        sizes[blk] = enc.overflow ? (u32)slot : bytes;
+        if (enc.overflow) rcx_flag(status, RCX_ST_CAPACITY, blk);
+    }
+}

@@ -327,7 +327,7 @@ def test_every_kernel_variant_is_bit_identical(oracle):
         for block in (4096, 65536):
             slots, sizes = oracle.encode_blocks(data, block, threads=8)
             ref_payload, ref_offsets = oracle.compact(slots, sizes)
-            for enc in ("0", "1", "2"):
+            for enc in ("0", "1", "2", "3"):
                 for dec in ("1", "4", "8"):
                     os.environ["RCX_ENC_VARIANT"], os.environ["RCX_LANES_PER_BLOCK"] = enc, dec
                     c = rcx.Context(0)
