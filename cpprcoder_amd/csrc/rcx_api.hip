@@ -320,8 +320,8 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
         Timed t(c, s, RCX_T_DECODE);
         if (coder == RCX_CODER_STATIC) {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
-            hipLaunchKernelGGL(rcx_dec_static_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
-                               block, n, static_cast<u8*>(d_dst), c->status);
+            hipLaunchKernelGGL(rcx_dec_static_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
+                               block, n, static_cast<u8*>(d_dst), c->status, static_cast<u32*>(nullptr));
         } else if (decode_lanes(c, nblocks) == 4) {
             const u32 grid = (u32)((nblocks + RCX_QUAD_BLOCKS - 1) / RCX_QUAD_BLOCKS);
             hipLaunchKernelGGL(rcx_dec_quad_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
@@ -413,7 +413,7 @@ int rcx_stream_encode(rcx_ctx* c, int coder, const uint8_t* src, uint32_t n,
                       uint8_t* dst, uint64_t sink_capacity, uint64_t* dst_size, uint32_t* request_size)
 {
     if (!c || !dst || !dst_size || (n && !src)) return RCX_E_ARG;
-    if (coder != RCX_CODER_ADAPTIVE || n > RCX_MAX_BLOCK) return RCX_E_ARG;
+    if ((coder != RCX_CODER_ADAPTIVE && coder != RCX_CODER_STATIC) || n > RCX_MAX_BLOCK) return RCX_E_ARG;
     HIP_TRY(hipSetDevice(c->device));
     *dst_size = 0;
     if (request_size) *request_size = 0;
@@ -424,6 +424,21 @@ int rcx_stream_encode(rcx_ctx* c, int coder, const uint8_t* src, uint32_t n,
     if (r != RCX_OK) return r;
     if (n) HIP_TRY(hipMemcpy(c->h_in, src, n, hipMemcpyHostToDevice));
     const u64 slot = rcx_block_bound(block);
+    if (coder == RCX_CODER_STATIC) {
+        // RangeEncoder<T>::encode (cpprcoder.h:375-458) returns a bool; the caller (the facade) replays the
+        // sink calls itself, so the whole stream is handed back: RCX_OK, or RCX_E_CAPACITY if dst is too small.
+        hipLaunchKernelGGL(rcx_enc_static_k, dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)n, block, (u64)1, c->slots, slot,
+                           c->sizes, c->status);
+        if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
+        r = rcx_ctx_sync_status(c, nullptr, nullptr);
+        if (r != RCX_OK) return r;
+        u32 ssize = 0;
+        HIP_TRY(hipMemcpy(&ssize, c->sizes, sizeof(u32), hipMemcpyDeviceToHost));
+        *dst_size = ssize;
+        if (ssize > sink_capacity) return RCX_E_CAPACITY;
+        HIP_TRY(hipMemcpy(dst, c->slots, ssize, hipMemcpyDeviceToHost));
+        return RCX_OK;
+    }
     hipLaunchKernelGGL(rcx_enc_adaptive_k<false>, dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)n, block, (u64)1, c->slots, slot,
                        c->sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr));
     if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
@@ -456,10 +471,42 @@ int rcx_stream_decode(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
                       uint8_t* dst, uint64_t sink_capacity, uint64_t* dst_size, uint32_t* request_size)
 {
     if (!c || !dst || !dst_size || (comp_size && !comp)) return RCX_E_ARG;
-    if (coder != RCX_CODER_ADAPTIVE || comp_size > 0x7FFFFFFFull) return RCX_E_ARG;
+    if ((coder != RCX_CODER_ADAPTIVE && coder != RCX_CODER_STATIC) || comp_size > 0x7FFFFFFFull) return RCX_E_ARG;
     HIP_TRY(hipSetDevice(c->device));
     *dst_size = 0;
     if (request_size) *request_size = 0;
+    if (coder == RCX_CODER_STATIC) {
+        // RangeEncoder<T>::decode (cpprcoder.h:460-519): bool.  RCX_OK = true; RCX_ERROR = false, with the
+        // symbols written before the failure in dst; a full sink is the caller's to notice (it replays writeByte).
+        if (comp_size < 516) return RCX_ERROR;                       // :468-476
+        const u32 declared = (u32)comp[0] | ((u32)comp[1] << 8) | ((u32)comp[2] << 16) | ((u32)comp[3] << 24);
+        if (declared == 0) return RCX_OK;                            // :481-483
+        if (comp_size < 516 + 1 || comp_size - 516 < 5) return RCX_ERROR; // :486-493
+        const u64 count = declared < sink_capacity ? declared : sink_capacity;
+        if (count > RCX_MAX_BLOCK) return RCX_E_ARG;
+        if (count == 0) return RCX_OK; // nothing fits: the caller's first writeByte fails
+        const u32 block = count < RCX_MIN_BLOCK ? RCX_MIN_BLOCK : (u32)count;
+        int r = grow(reinterpret_cast<void**>(&c->h_in), &c->h_in_bytes, comp_size + 64);
+        if (r != RCX_OK) return r;
+        r = grow(reinterpret_cast<void**>(&c->h_out), &c->h_out_bytes, count + 64);
+        if (r != RCX_OK) return r;
+        u64 off_bytes = c->h_off_count * sizeof(u64);
+        r = grow(reinterpret_cast<void**>(&c->h_off), &off_bytes, 2 * sizeof(u64));
+        if (r != RCX_OK) return r;
+        c->h_off_count = off_bytes / sizeof(u64);
+        const u64 offs[2] = {0, comp_size};
+        HIP_TRY(hipMemcpy(c->h_in, comp, comp_size, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->h_off, offs, sizeof(offs), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(rcx_dec_static_k<true>, dim3(1), dim3(64), 0, nullptr, c->h_in, c->h_off, (u64)1, block, count, c->h_out,
+                           c->status, c->status + 2);
+        if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
+        HIP_TRY(hipMemcpy(c->status_host, c->status, 4 * sizeof(u32), hipMemcpyDeviceToHost));
+        const u32 short_at = c->status_host[2];
+        const u64 produced = short_at < count ? short_at : count;
+        if (produced) HIP_TRY(hipMemcpy(dst, c->h_out, produced, hipMemcpyDeviceToHost));
+        *dst_size = produced;
+        return short_at < count ? RCX_ERROR : RCX_OK;
+    }
     if (comp_size < 8) { // cpprcoder.h:878-880
         if (request_size) *request_size = 8;
         return RCX_PENDING;

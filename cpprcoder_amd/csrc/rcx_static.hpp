@@ -136,8 +136,11 @@ __global__ __launch_bounds__(64) void rcx_enc_static_k(const u8* __restrict__ sr
 // ===========================================================================
 // Static decode
 // ===========================================================================
+// STREAM = the single-stream entry point: one block whose symbol count n the host took from the header;
+// track[0] = first symbol whose renormalisation ran out of input (cpprcoder.h:506-509), or 0xFFFFFFFF.
+template <bool STREAM>
 __global__ __launch_bounds__(64) void rcx_dec_static_k(const u8* __restrict__ comp, const u64* __restrict__ offsets, u64 nblocks,
-                                                       u32 block, u64 n, u8* __restrict__ dst, u32* status)
+                                                       u32 block, u64 n, u8* __restrict__ dst, u32* status, u32* track)
 {
     __shared__ u32 lds[RCX_STATIC_LDS_DW + RCX_RING_DW * RCX_LANES];
     const u32 lane = threadIdx.x;
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(64) void rcx_dec_static_k(const u8* __restrict__ co
         bool good = s1 >= s0 && stream_len >= RCX_STATIC_HEADER + 5;
         if (good) {
             const u32 declared = (u32)s[0] | ((u32)s[1] << 8) | ((u32)s[2] << 16) | ((u32)s[3] << 24);
-            good = declared == len;
+            good = STREAM || declared == len;
         }
         if (good) {
             for (u32 i = 0; i < 256; ++i) tab.set(i, (u32)s[4 + 2 * i] | ((u32)s[5 + 2 * i] << 8)); // :585-602
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(64) void rcx_dec_static_k(const u8* __restrict__ co
             dec.low = ((u32)h[4] << 24) | ((u32)h[5] << 16) | ((u32)h[6] << 8) | (u32)h[7];
             dec.range = 0xFFFFFFFFu;
         } else {
-            rcx_flag(status, RCX_ST_CORRUPT, blk);
+            if (!STREAM) rcx_flag(status, RCX_ST_CORRUPT, blk);
             live = false;
             len = 0;
         }
@@ -191,9 +194,10 @@ __global__ __launch_bounds__(64) void rcx_dec_static_k(const u8* __restrict__ co
     for (u32 q = 0; q < 15; ++q) coarse[q] = tab.get(16 * (q + 1));
 
     const u32 maxlen = rcx_wave_max(len);
-    const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+    const bool full = !STREAM && __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
     u8* out = dst + at;
     bool bad = false;
+    u32 short_at = 0xFFFFFFFFu;
 
     // One symbol, cpprcoder.h:500-517.  find() (:521-535) returns the number of entries cum[1..255] that
     // are <= target (the table is non-decreasing), counted here in two levels of 15 probes.
@@ -250,10 +254,15 @@ __global__ __launch_bounds__(64) void rcx_dec_static_k(const u8* __restrict__ co
                 u32 sym;
                 RCX_STATIC_SYMBOL(sym);
                 out[i] = (u8)sym;
+                if (STREAM && short_at == 0xFFFFFFFFu && (bad || dec.taken() + (RCX_STATIC_HEADER - 3) > stream_len)) short_at = i;
             }
         }
     }
 #undef RCX_STATIC_SYMBOL
     // cpprcoder.h:506-509: running out of input inside the renormalisation is a failure
-    if (live && (bad || dec.taken() + (RCX_STATIC_HEADER - 3) > stream_len)) rcx_flag(status, RCX_ST_CORRUPT, blk);
+    if (STREAM) {
+        if (lane == 0) track[0] = live ? short_at : 0u;
+    } else if (live && (bad || dec.taken() + (RCX_STATIC_HEADER - 3) > stream_len)) {
+        rcx_flag(status, RCX_ST_CORRUPT, blk);
+    }
 }

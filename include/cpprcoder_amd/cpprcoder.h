@@ -9,6 +9,7 @@
  *     IStream<T> / MemoryStream            cpprcoder.h:130-247, 964-1077
  *     AdaptiveRangeEncoder<T>              cpprcoder.h:626-802
  *     AdaptiveRangeDecoder<T>              cpprcoder.h:809-940
+ *     RangeEncoder<T> (static coder)       cpprcoder.h:321-619
  * but the coding itself runs on the GPU (rcx_stream_encode / rcx_stream_decode).
  *
  * What differs, by design:
@@ -304,6 +305,63 @@ private:
     u32 outSize_;
     bool done_;
     std::vector<u8> fed_;
+};
+
+//--- RangeEncoder: the static two-pass coder (cpprcoder.h:321-619); encode and decode are members of one class
+template<class T = MemoryStream>
+class RangeEncoder
+{
+public:
+    static const u32 MAX_SIZE = 0x7FFFFFFFU;
+    static const u32 FREQUENCY_SIZE = 256;
+    static const u32 HeaderSize16 = sizeof(u32) + sizeof(u16) * FREQUENCY_SIZE;
+
+    RangeEncoder() {}
+
+    // cpprcoder.h:375-458: header and table through write(), every payload byte through writeByte(),
+    // the last four bytes through write(); false as soon as the sink refuses one.
+    bool encode(T& stream, u32 size, const u8* bytes)
+    {
+        CPPRCODER_ASSERT(size <= MAX_SIZE);
+        rcx_ctx* ctx = facade_context();
+        if (!ctx || RCX_MAX_BLOCK < size) return false;
+        std::vector<u8> out(static_cast<size_t>(rcx_block_bound(size < RCX_MIN_BLOCK ? RCX_MIN_BLOCK : size)) + 64);
+        uint64_t total = 0;
+        if (rcx_stream_encode(ctx, RCX_CODER_STATIC, bytes, size, out.data(), out.size(), &total, nullptr) != RCX_OK) return false;
+        if (stream.write(4, out.data()) <= 0) return false;
+        for (u32 i = 0; i < 4; ++i) { // write16(): 4 x 64 counts (cpprcoder.h:604-619)
+            if (stream.write(128, out.data() + 4 + 128 * i) <= 0) return false;
+        }
+        const uint64_t payload_end = total - 4;
+        for (uint64_t i = HeaderSize16; i < payload_end; ++i) {
+            if (!stream.writeByte(out[i])) return false;
+        }
+        return 0 < stream.write(4, out.data() + payload_end);
+    }
+
+    // cpprcoder.h:460-519
+    bool decode(T& stream, u32 size, const u8* bytes)
+    {
+        CPPRCODER_ASSERT(size <= MAX_SIZE);
+        rcx_ctx* ctx = facade_context();
+        if (!ctx) return false;
+        if (size < HeaderSize16) return false;
+        const u32 declared = static_cast<u32>(bytes[0]) | (static_cast<u32>(bytes[1]) << 8) | (static_cast<u32>(bytes[2]) << 16) |
+                             (static_cast<u32>(bytes[3]) << 24);
+        if (declared == 0) return true;
+        std::vector<u8> out(static_cast<size_t>(declared) + 64);
+        uint64_t produced = 0;
+        int st = rcx_stream_decode(ctx, RCX_CODER_STATIC, bytes, size, out.data(), declared, &produced, nullptr);
+        if (st != RCX_OK && st != RCX_ERROR) return false;
+        for (uint64_t i = 0; i < produced; ++i) {
+            if (!stream.writeByte(out[i])) return false;
+        }
+        return st == RCX_OK;
+    }
+
+private:
+    RangeEncoder(const RangeEncoder&) = delete;
+    RangeEncoder& operator=(const RangeEncoder&) = delete;
 };
 
 //--- BlockCoder: the many-blocks entry point in the facade's vocabulary (new; the reference has

@@ -53,8 +53,10 @@ enum {
     RCX_E_NOMEM = -6     /* device or host allocation failed */
 };
 
-/* Which coder a call uses.  The block entry points take either; the single-stream entry points
- * (rcx_stream_*) take RCX_CODER_ADAPTIVE only. */
+/* Which coder a call uses.  With RCX_CODER_STATIC the single-stream entry points have the bool semantics of
+ * RangeEncoder<T>::encode / decode (cpprcoder.h:336-337): RCX_OK = true, RCX_ERROR = false; encode hands back
+ * the whole stream (the caller replays write / writeByte on its sink), decode the symbols written before a
+ * failure; request_size is not used. */
 enum {
     RCX_CODER_ADAPTIVE = 0, /* AdaptiveRangeEncoder/Decoder, cpprcoder.h:626-940 */
     RCX_CODER_STATIC = 1    /* RangeEncoder (two-pass, 516-byte table header), cpprcoder.h:321-619 */

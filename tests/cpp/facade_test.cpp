@@ -5,6 +5,7 @@
 //
 //   facade_test enc  <in> <out> <sink_capacity> <piece>   piece: 0 = one call, N = pieces of N bytes, -1 = encode(u8)
 //   facade_test dec  <in> <out> <sink_capacity> <piece>
+//   facade_test senc|sdec <in> <out> <sink_capacity>       static RangeEncoder<>::encode / decode
 //   facade_test blocks <in> <out> <block>                  BlockCoder round trip; out = compacted streams
 #include <cstdio>
 #include <cstdlib>
@@ -76,6 +77,16 @@ int main(int argc, char** argv)
         }
         dump(argv[3], sink.get(), static_cast<size_t>(sink.size()));
         printf("%d %u %d %d\n", static_cast<int>(r.status_), r.requestSize_, sink.size(), sink.capacity());
+        return 0;
+    }
+    if (!strcmp(argv[1], "senc") || !strcmp(argv[1], "sdec")) { // static coder: test/main.cpp:270-283
+        s32 cap = atoi(argv[4]);
+        MemoryStream sink(cap);
+        RangeEncoder<> coder;
+        bool ok = !strcmp(argv[1], "senc") ? coder.encode(sink, static_cast<u32>(in.size()), in.data())
+                                           : coder.decode(sink, static_cast<u32>(in.size()), in.data());
+        dump(argv[3], sink.get(), static_cast<size_t>(sink.size()));
+        printf("%d 0 %d %d\n", ok ? 1 : 0, sink.size(), sink.capacity());
         return 0;
     }
     if (!strcmp(argv[1], "blocks")) {

@@ -74,3 +74,28 @@ def test_facade_block_coder(exe, tmp_path, oracle):
     slots, sizes = oracle.encode_blocks(data, 65536, threads=4)
     payload, offsets = oracle.compact(slots, sizes)
     assert total == len(payload) and noff == len(offsets) and comp == payload.tobytes()
+
+
+def test_facade_static_range_encoder(exe, tmp_path, oracle):
+    """RangeEncoder<>::encode / decode (cpprcoder.h:375-519) through the facade: same bytes, same bool."""
+    files = workloads.canterbury_files()
+    cases = [b"", b"hello world", bytes(range(256)), b"A" * 65536, workloads.zipf(30000, 2).tobytes(), files["alice29.txt"], files["sum"]]
+    for v in cases:
+        n = len(v)
+        ok_ref, ref, size_ref = oracle.static_encode(v, sink_capacity=n + n // 32 + 2048)
+        (ok, _, size, _), out = run(exe, tmp_path, "senc", v, n + n // 32 + 2048)
+        assert (bool(ok), size) == (ok_ref, size_ref) and out == ref, n
+        (ok, _, size, _), back = run(exe, tmp_path, "sdec", ref, max(n, 16))
+        assert ok == 1 and back == v
+    # a sink that fills: false, and the sink holds what had been written (cpprcoder.h:409-427)
+    v = workloads.uniform(5000, 4).tobytes()
+    full = oracle.static_encode(v)[1]
+    for cap in (600, 1000, len(full) - 6):
+        ok_ref, ref, size_ref = oracle.static_encode(v, sink_capacity=cap)
+        (ok, _, size, _), out = run(exe, tmp_path, "senc", v, cap)
+        assert (bool(ok), size) == (ok_ref, size_ref) and out[: len(ref)] == ref, cap
+    # truncated input and a too-small sink on decode: false, with the symbols decoded so far
+    for piece, cap in ((full[: len(full) // 2], 5000), (full[:520], 5000), (full[:516], 5000), (full[:100], 5000), (full, 1000)):
+        ok_ref, ref, size_ref = oracle.static_decode(piece, cap)
+        (ok, _, size, _), out = run(exe, tmp_path, "sdec", piece, cap)
+        assert (bool(ok), size) == (ok_ref, size_ref) and out[: len(ref)] == ref, (len(piece), cap)
