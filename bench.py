@@ -93,6 +93,8 @@ def main() -> None:
     ap.add_argument("--block", type=int, default=BLOCK)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=256)
+    ap.add_argument("--exchange", action="store_true",
+                    help="run the N>1 exchange step (allgatherv over RCCL) even with one rank: rehearses that code path on a 1-GPU box")
     args = ap.parse_args()
 
     import torch
@@ -111,9 +113,11 @@ def main() -> None:
     build.build()  # no-op when the in-tree librcx.so is current
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    exchange = world > 1 or args.exchange
+    if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     n, block = args.bytes, args.block
     nblocks = rcx.block_count(n, block)
@@ -122,17 +126,18 @@ def main() -> None:
     ctx = rcx.Context(local)
     ctx.reserve(n, block)
     bound = rcx.encode_bound(n, block)
-    comp = torch.empty(bound, dtype=torch.uint8, device=device)
+    comp = torch.empty(bound + 256, dtype=torch.uint8, device=device)  # +256: the exchange pads segments to 256 B
     offs = torch.zeros(nblocks + 1, dtype=torch.int64, device=device)
     out = torch.empty(n, dtype=torch.uint8, device=device)
-    concat = torch.empty(bound * world, dtype=torch.uint8, device=device) if world > 1 else None
-    side = torch.cuda.Stream(device=device) if world > 1 else None
+    concat = torch.empty((bound + 256) * world, dtype=torch.uint8, device=device) if exchange else None
+    staging = torch.empty((bound + 256) * world, dtype=torch.uint8, device=device) if exchange else None
+    side = torch.cuda.Stream(device=device) if exchange else None
     main_stream = torch.cuda.current_stream()
     gather_ms = []
 
     def step():
         ctx.encode_blocks_device(src, block, comp, offs)
-        if world == 1:
+        if not exchange:
             # the decoder takes the block table from HBM: no host round trip inside the step
             ctx.decode_blocks_device(comp, bound, offs, n, block, out)
             return
@@ -142,7 +147,7 @@ def main() -> None:
         with torch.cuda.stream(side):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            bases, sizes, works = parallel.allgatherv_segments(comp, total, concat)
+            bases, sizes, works = parallel.allgatherv_segments(comp, total, concat, staging=staging)
             table = parallel.allgather_offsets(offs, bases)
             for w in works:
                 w.wait()
@@ -153,7 +158,7 @@ def main() -> None:
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if exchange:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -179,7 +184,7 @@ def main() -> None:
     total = int(offs[-1])
     ratio = total / n
 
-    if world > 1:
+    if exchange:
         t = torch.tensor([wall], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t[0])
@@ -219,7 +224,7 @@ def main() -> None:
                                    f"encode+decode round trip resident in HBM (BASELINE.json configs[1])",
                        "bytes_per_gpu": n, "block": block, "blocks_per_gpu": nblocks,
                        "parallelism": f"blocks sharded over {world} GPU(s), one process per GPU"
-                                      + ("; allgatherv of the compressed segments overlapped with decode" if world > 1 else "")},
+                                      + ("; allgatherv of the compressed segments overlapped with decode" if exchange else "")},
             "roundtrip_ok": roundtrip_ok, "ratio": round(ratio, 6),
             "encode_MBps": round(n / 1e6 / ((enc_ms + scan_ms + scat_ms) * 1e-3), 1),
             "decode_MBps": round(n / 1e6 / (dec_ms * 1e-3), 1),
@@ -231,7 +236,7 @@ def main() -> None:
                                  "blocks_in_flight x clock / cycles_per_symbol (DESIGN.md), not HBM"},
             "workload_gen_s": round(gen_s, 2),
         }
-        if world > 1 and gather_ms:
+        if exchange and gather_ms:
             line["allgatherv_ms"] = round(sum(a.elapsed_time(b) for a, b in gather_ms) / len(gather_ms), 3)
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -243,7 +248,7 @@ def main() -> None:
         print(json.dumps(line), flush=True)
 
     ctx.close()
-    if world > 1:
+    if exchange:
         dist.destroy_process_group()
 
 

@@ -41,13 +41,18 @@ def _worker(rank: int, world: int, port: int, ret):
         chk = oracle_lib.oracle()
         slots, sizes = chk.encode_blocks(shard, block)
         payload, offsets = chk.compact(slots, sizes)
-        seg = torch.zeros(len(payload) + 100, dtype=torch.uint8)
+        seg = torch.zeros(len(payload) + 8192, dtype=torch.uint8)
         seg[: len(payload)] = torch.from_numpy(payload)
-        concat = torch.zeros(world * (len(payload) + 4096), dtype=torch.uint8)
+        concat = torch.zeros(world * (len(payload) + 8192), dtype=torch.uint8)
         bases, seg_sizes, works = parallel.allgatherv_segments(seg, len(payload), concat)
         table = parallel.allgather_offsets(torch.from_numpy(offsets.astype(np.int64)), bases)
-        for w in works:
+        assert works == []
+        # the per-root broadcast form must give the same bytes
+        concat_b = torch.zeros_like(concat)
+        bases_b, sizes_b, works_b = parallel.allgatherv_segments(seg, len(payload), concat_b, method="broadcast")
+        for w in works_b:
             w.wait()
+        assert bases_b == bases and sizes_b == seg_sizes and torch.equal(concat_b[: sum(seg_sizes)], concat[: sum(seg_sizes)])
         assert seg_sizes[rank] == len(payload) and table.numel() == nblocks + 1
         total = int(table[-1])
         assert total == sum(seg_sizes)
