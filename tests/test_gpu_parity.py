@@ -342,3 +342,58 @@ def test_every_kernel_variant_is_bit_identical(oracle):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_streams_and_graph_replay(ctx, oracle):
+    """The device entry points only enqueue work on the caller's stream (no allocation after
+    rcx_ctx_reserve, no host sync), so they run on a side stream and can be captured into a HIP graph."""
+    from cpprcoder_amd import rcx
+    n, block = 65536 * 64 + 100, 65536
+    data = workloads.zipf(n, 77)
+    slots, sizes = oracle.encode_blocks(data, block, threads=8)
+    ref_payload, ref_offsets = oracle.compact(slots, sizes)
+    src = torch.from_numpy(data).cuda()
+    nblocks = rcx.block_count(n, block)
+    dst = torch.zeros(rcx.encode_bound(n, block), dtype=torch.uint8, device="cuda")
+    offs = torch.zeros(nblocks + 1, dtype=torch.int64, device="cuda")
+    out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    ctx.reserve(n, block)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ctx.encode_blocks_device(src, block, dst, offs)
+        ctx.decode_blocks_device(dst, dst.numel(), offs, n, block, out)
+        ctx.sync_status()
+    side.synchronize()
+    assert np.array_equal(offs.cpu().numpy().astype(np.uint64), ref_offsets)
+    assert np.array_equal(dst[: int(ref_offsets[-1])].cpu().numpy(), ref_payload) and torch.equal(out, src)
+    # capture once, replay on new input
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ctx.encode_blocks_device(src, block, dst, offs)
+        ctx.decode_blocks_device(dst, dst.numel(), offs, n, block, out)
+    data2 = workloads.canterbury_tiled(n)
+    src.copy_(torch.from_numpy(data2).cuda())
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    ctx.sync_status()
+    s2, z2 = oracle.encode_blocks(data2, block, threads=8)
+    p2, o2 = oracle.compact(s2, z2)
+    assert np.array_equal(offs.cpu().numpy().astype(np.uint64), o2)
+    assert np.array_equal(dst[: int(o2[-1])].cpu().numpy(), p2) and torch.equal(out, src)
+
+
+def test_many_small_random_buffers(ctx, oracle):
+    rs = np.random.RandomState(4242)
+    for _ in range(60):
+        block = int(rs.choice([16, 17 * 16, 256, 1000, 4096]))
+        n = int(rs.randint(1, 40000))
+        alpha = int(rs.choice([1, 2, 3, 16, 200, 256]))
+        data = rs.randint(0, alpha, size=n).astype(np.uint8)
+        coder = int(rs.randint(2))
+        slots, sizes = oracle.encode_blocks(data, block, coder=coder, threads=4)
+        payload, offsets, _ = gpu_encode(ctx, data, block, coder=coder, src_offset=int(rs.randint(4)))
+        assert_same_blocks(payload, offsets, slots, sizes)
+        back, st, _ = gpu_decode(ctx, payload, offsets, n, block, coder=coder, comp_offset=int(rs.randint(16)))
+        assert st == 0 and np.array_equal(back, data), (block, n, alpha, coder)
