@@ -201,7 +201,7 @@ def main() -> None:
         dec_ms = timing["decode"]["ms"] / max(1, timing["decode"]["launches"])
         scan_ms = timing["scan"]["ms"] / max(1, timing["scan"]["launches"])
         scat_ms = timing["scatter"]["ms"] / max(1, timing["scatter"]["launches"])
-        auto = "rcx_dec_oct_k" if 12288 < nblocks < 24576 else "rcx_dec_quad_k"  # rcx_api.hip: decode_lanes()
+        auto = "rcx_dec_quad_k"  # rcx_api.hip: decode_lanes()
         dec_name = {"1": "rcx_dec_adaptive_k", "4": "rcx_dec_quad_k", "8": "rcx_dec_oct_k"}.get(os.environ.get("RCX_LANES_PER_BLOCK", ""), auto)
         enc_name = {"0": "rcx_enc_adaptive_k", "1": "rcx_enc_oct_k", "2": "rcx_enc_mc_k"}.get(os.environ.get("RCX_ENC_VARIANT", ""), "rcx_enc_mc5_k")
         dom, dom_ms = (dec_name, dec_ms) if dec_ms >= enc_ms else (enc_name, enc_ms)

@@ -34,6 +34,7 @@ struct EventPair {
 struct rcx_ctx {
     int device = 0;
     int lanes_per_block = 0; // decode: 0 = pick by block count (default), 8 = octet, 4 = quad, 1 = one lane per block (RCX_LANES_PER_BLOCK)
+    int wide_wg = -1;        // decode workgroups: -1 = pick by block count, 1 = multi-wave, 0 = single-wave (RCX_WIDE_WG)
     int enc_variant = 3;     // encode: 0 = one wave per 64 blocks, 1 = octet, 2 = 4-wave model/coder split, 3 = 5-wave split (RCX_ENC_VARIANT)
     // scratch
     u8* slots = nullptr;
@@ -124,6 +125,13 @@ bool block_ok(uint32_t block) { return block >= RCX_MIN_BLOCK && block <= RCX_MA
 // wait.  Measured on 1 GiB (profiles/): the quad kernel wins whenever it either gets >= 2 waves per SIMD
 // (>= 32768 blocks) or cannot fill the SIMDs anyway (<= 8192 blocks); around 16384 blocks -- where quad
 // is exactly one wave per SIMD and octet two -- the octet kernel wins.
+// Multi-wave workgroups (waves spread over the SIMDs of one CU) or single-wave ones (more waves per CU).
+bool wide_workgroups(const rcx_ctx* c, u64 nblocks)
+{
+    if (c->wide_wg >= 0) return c->wide_wg != 0;
+    return nblocks <= 49152; // measured (profiles/): 32768 blocks 56.0 vs 47.7 GB/s, 65536 blocks 55.8 vs 61.1
+}
+
 int decode_lanes(const rcx_ctx* c, u64 nblocks)
 {
     if (c->lanes_per_block) return c->lanes_per_block;
@@ -191,6 +199,7 @@ int rcx_ctx_create(int device, rcx_ctx** out)
     if (!c) return RCX_E_NOMEM;
     c->device = device;
     if (const char* v = getenv("RCX_LANES_PER_BLOCK")) c->lanes_per_block = (atoi(v) == 1 || atoi(v) == 4 || atoi(v) == 8) ? atoi(v) : 0;
+    if (const char* v = getenv("RCX_WIDE_WG")) c->wide_wg = atoi(v) ? 1 : 0;
     if (const char* v = getenv("RCX_ENC_VARIANT")) c->enc_variant = atoi(v) >= 0 && atoi(v) <= 3 ? atoi(v) : 3;
     if (hipMalloc(reinterpret_cast<void**>(&c->status), 4 * sizeof(u32)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&c->status_host), 4 * sizeof(u32), hipHostMallocDefault) != hipSuccess) {
@@ -323,13 +332,29 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
             hipLaunchKernelGGL(rcx_dec_static_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
                                block, n, static_cast<u8*>(d_dst), c->status, static_cast<u32*>(nullptr));
         } else if (decode_lanes(c, nblocks) == 4) {
-            const u32 grid = (u32)((nblocks + RCX_QUAD_BLOCKS - 1) / RCX_QUAD_BLOCKS);
-            hipLaunchKernelGGL(rcx_dec_quad_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
-                               block, n, static_cast<u8*>(d_dst), c->divtab, c->status);
+            if (wide_workgroups(c, nblocks)) {
+                const u64 per_wg = RCX_QUAD_BLOCKS * RCX_QUAD_DEC_WAVES;
+                const u32 grid = (u32)((nblocks + per_wg - 1) / per_wg);
+                hipLaunchKernelGGL(rcx_dec_quad_k<RCX_QUAD_DEC_WAVES>, dim3(grid), dim3(64 * RCX_QUAD_DEC_WAVES), 0, s,
+                                   static_cast<const u8*>(d_comp), d_offsets, nblocks, block, n, static_cast<u8*>(d_dst), c->divtab,
+                                   c->status);
+            } else {
+                const u32 grid = (u32)((nblocks + RCX_QUAD_BLOCKS - 1) / RCX_QUAD_BLOCKS);
+                hipLaunchKernelGGL(rcx_dec_quad_k<1>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
+                                   block, n, static_cast<u8*>(d_dst), c->divtab, c->status);
+            }
         } else if (decode_lanes(c, nblocks) == 8) {
-            const u32 grid = (u32)((nblocks + RCX_OCT_BLOCKS - 1) / RCX_OCT_BLOCKS);
-            hipLaunchKernelGGL(rcx_dec_oct_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
-                               block, n, static_cast<u8*>(d_dst), c->divtab, c->status);
+            if (wide_workgroups(c, nblocks)) {
+                const u64 per_wg = RCX_OCT_BLOCKS * RCX_OCT_DEC_WAVES;
+                const u32 grid = (u32)((nblocks + per_wg - 1) / per_wg);
+                hipLaunchKernelGGL(rcx_dec_oct_k<RCX_OCT_DEC_WAVES>, dim3(grid), dim3(64 * RCX_OCT_DEC_WAVES), 0, s,
+                                   static_cast<const u8*>(d_comp), d_offsets, nblocks, block, n, static_cast<u8*>(d_dst), c->divtab,
+                                   c->status);
+            } else {
+                const u32 grid = (u32)((nblocks + RCX_OCT_BLOCKS - 1) / RCX_OCT_BLOCKS);
+                hipLaunchKernelGGL(rcx_dec_oct_k<1>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
+                                   block, n, static_cast<u8*>(d_dst), c->divtab, c->status);
+            }
         } else {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_dec_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets,
