@@ -360,8 +360,8 @@ struct DecLane {
     u32 low, range;
     u64 win;            // upcoming stream bytes, left-aligned (next byte on top)
     u32 navail8;        // 8 * bytes in win
-    u32 ahead;          // the dword after the window, fetched from the ring one refill early; RAW (memory
-                        // order) so that nothing touches it -- and waits for it -- before the next refill
+    u32 ahead;          // the dword after the window, taken from the ring one refill early; RAW (memory order)
+    u32 peek;           // ring[rd], read one symbol early so that its LDS latency is never waited for
     // The compressed stream reaches the window through a per-lane ring of RCX_RING_DW dwords in LDS that
     // is topped up every 16 symbols with 16-byte global loads issued one top-up ahead.  (Loading the
     // window straight from global memory puts a vmcnt wait -- which also waits for the older output
@@ -433,6 +433,7 @@ struct DecLane {
         win = (u64)(rcx_bswap(ring_get()) << (8 * skew)) << 32;
         navail8 = 32 - 8 * skew;
         ahead = ring_get();
+        peek = ring[(rd % RCX_RING_DW) * RCX_LANES];
         short_at = 0xFFFFFFFFu;
         return declared;
     }
@@ -445,6 +446,7 @@ struct DecLane {
         win = 0;
         navail8 = 64;
         ahead = 0;
+        peek = 0;
         ring = ring_column;
         rd = wr = 0;
         npend = 0;
@@ -477,11 +479,16 @@ struct DecLane {
     // needed before the next top-up (a few symbols later), so no latency is exposed here.
     RCX_DEV void pull()
     {
-        if (navail8 <= 32) {
-            win |= (u64)rcx_bswap(ahead) << (32 - navail8);
-            navail8 += 32;
-            ahead = ring_get();
-        }
+        // branch-free: some lane of a wave tops up on almost every symbol, and without a branch the
+        // compiler can schedule across symbols (the ring is read unconditionally; the value is only kept
+        // by the lanes that needed it)
+        const bool need = navail8 <= 32;
+        const u64 add = need ? (u64)rcx_bswap(ahead) << ((32 - navail8) & 63u) : 0;
+        win |= add;
+        navail8 += need ? 32u : 0u;
+        ahead = need ? peek : ahead;
+        rd += need ? 1u : 0u;
+        peek = ring[(rd % RCX_RING_DW) * RCX_LANES]; // for the next symbol
         const u32 k8 = rcx_clz(range) & 0x18u;
         low = (u32)((((u64)low << 32) | (u32)(win >> 32)) << k8 >> 32);
         win <<= k8;
