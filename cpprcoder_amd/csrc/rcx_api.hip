@@ -120,11 +120,6 @@ int ensure_divtab(rcx_ctx* c, u32 block)
 
 bool block_ok(uint32_t block) { return block >= RCX_MIN_BLOCK && block <= RCX_MAX_BLOCK; }
 
-// Lanes per block for the adaptive decoder.  A wave-instruction costs its SIMD 4 cycles whatever it
-// serves, so fewer lanes per block means less machine-wide work, but a lone wave per SIMD exposes every
-// wait.  Measured on 1 GiB (profiles/): the quad kernel wins whenever it either gets >= 2 waves per SIMD
-// (>= 32768 blocks) or cannot fill the SIMDs anyway (<= 8192 blocks); around 16384 blocks -- where quad
-// is exactly one wave per SIMD and octet two -- the octet kernel wins.
 // Multi-wave workgroups (waves spread over the SIMDs of one CU) or single-wave ones (more waves per CU).
 bool wide_workgroups(const rcx_ctx* c, u64 nblocks)
 {
@@ -132,10 +127,15 @@ bool wide_workgroups(const rcx_ctx* c, u64 nblocks)
     return nblocks <= 49152; // measured (profiles/): 32768 blocks 56.0 vs 47.7 GB/s, 65536 blocks 55.8 vs 61.1
 }
 
+// Lanes per block for the adaptive decoder.  A wave-instruction costs its SIMD 4 cycles whatever it
+// serves, so fewer lanes per block means less machine-wide work: with its waves placed one per SIMD
+// (multi-wave workgroups) the quad kernel beats the octet kernel at every block count measured on 1 GiB
+// (4 KiB ... 256 KiB blocks, profiles/r01s_decode_variants.jsonl).  The octet and one-lane kernels stay
+// selectable.
 int decode_lanes(const rcx_ctx* c, u64 nblocks)
 {
-    if (c->lanes_per_block) return c->lanes_per_block;
-    return (nblocks > 12288 && nblocks < 24576) ? 8 : 4;
+    (void)nblocks;
+    return c->lanes_per_block ? c->lanes_per_block : 4;
 }
 
 int reserve(rcx_ctx* c, u64 n, u32 block)

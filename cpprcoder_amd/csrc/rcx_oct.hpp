@@ -689,8 +689,10 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
             stage[lane] = ahead;
             ahead = divtab[i0 + RCX_STAGE + lane];
             const u32 jend = (maxlen - i0) < RCX_STAGE ? (maxlen - i0) : RCX_STAGE;
+            // 64 decoded bytes are held and stored as four back-to-back 16-byte stores, so that L2 sees whole
+            // 64-byte pieces (16-byte pieces 16 symbols apart were written to HBM one by one: 4x WRITE_SIZE)
+            U4 held[4];
             for (u32 j0 = 0; j0 < jend; j0 += 16) {
-                const u32 i = i0 + j0;
                 u32 word[4] = {0, 0, 0, 0};
                 dec.topup();
                 DivEntry k_next = stage[j0];
@@ -702,14 +704,22 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
                     RCX_QUAD_DEC_SYMBOL(kk, sym);
                     word[s >> 2] |= sym << (8 * (s & 3));
                 }
-                if (leader) {
-                    U4 o;
-                    o.x = word[0];
-                    o.y = word[1];
-                    o.z = word[2];
-                    o.w = word[3];
-                    *reinterpret_cast<U4*>(out + i) = o;
-                }
+                U4 o;
+                o.x = word[0];
+                o.y = word[1];
+                o.z = word[2];
+                o.w = word[3];
+                if (j0 == 0) held[0] = o;
+                else if (j0 == 16) held[1] = o;
+                else if (j0 == 32) held[2] = o;
+                else held[3] = o;
+            }
+            if (leader) {
+                U4* o4 = reinterpret_cast<U4*>(out + i0);
+                o4[0] = held[0];
+                if (jend > 16) o4[1] = held[1];
+                if (jend > 32) o4[2] = held[2];
+                if (jend > 48) o4[3] = held[3];
             }
         }
     } else {

@@ -20,13 +20,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def short(name: str) -> str:
     name = name.replace("void ", "")
     base = name.split("(")[0]
-    return base if base.startswith("rcx_") else base[:48] + "...(torch)"
+    if base.startswith("rcx_"):
+        return base.split("<")[0]  # rcx_dec_quad_k<4> -> rcx_dec_quad_k
+    return base[:48] + "...(torch)"
 
 
 def main():
     tag, stats_dir = sys.argv[1], sys.argv[2]
     pmc_dirs = dict(a.split("=", 1) for a in sys.argv[4:]) if len(sys.argv) > 3 and sys.argv[3] == "--pmc" else {}
-    stats = glob.glob(os.path.join(stats_dir, "*", "*_kernel_stats.csv"))[0]
+    newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)
+    stats = newest(os.path.join(stats_dir, "*", "*_kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats)))
     with open(os.path.join(HERE, f"{tag}_kernel_stats.csv"), "w") as f:
         w = csv.DictWriter(f, fieldnames=rows[0].keys())
@@ -37,7 +40,7 @@ def main():
             w.writerow(r)
     counters = collections.defaultdict(dict)
     for label, d in pmc_dirs.items():
-        path = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
+        path = newest(os.path.join(d, "*", "*_counter_collection.csv"))
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(path)):
             if "rcx_" not in r["Kernel_Name"]:
