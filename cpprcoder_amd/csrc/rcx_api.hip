@@ -123,8 +123,8 @@ bool block_ok(uint32_t block) { return block >= RCX_MIN_BLOCK && block <= RCX_MA
 // Multi-wave workgroups (waves spread over the SIMDs of one CU) or single-wave ones (more waves per CU).
 bool wide_workgroups(const rcx_ctx* c, u64 nblocks)
 {
-    if (c->wide_wg >= 0) return c->wide_wg != 0;
-    return nblocks <= 49152; // measured (profiles/): 32768 blocks 56.0 vs 47.7 GB/s, 65536 blocks 55.8 vs 61.1
+    (void)nblocks;
+    return c->wide_wg != 0; // default: multi-wave (RCX_WIDE_WG=0 selects single-wave workgroups)
 }
 
 // Lanes per block for the adaptive decoder.  A wave-instruction costs its SIMD 4 cycles whatever it

@@ -366,7 +366,8 @@ struct DecLane {
     // is topped up every 16 symbols with 16-byte global loads issued one top-up ahead.  (Loading the
     // window straight from global memory puts a vmcnt wait -- which also waits for the older output
     // stores -- into every symbol: measured 430 cycles per symbol.)
-    u32* ring;          // this lane's ring column: dword d lives at ring[(d % RCX_RING_DW) * RCX_LANES]
+    u32* ring;          // this block's ring column: dword d lives at ring[(d % RCX_RING_DW) * stride]
+    u32 stride;         // columns in the ring image (64 with one lane per block; lanes of one block share a column)
     u32 rd, wr;         // dwords taken from / written to the ring so far, counted from `origin`
     const u8* origin;   // 16-byte aligned address of ring dword 0
     U4 pend0, pend1, pend2, pend3; // pieces requested at the previous top-up, not yet in the ring
@@ -400,24 +401,25 @@ struct DecLane {
     }
     RCX_DEV void ring_put(const U4& piece)
     {
-        u32* at = ring + (wr % RCX_RING_DW) * RCX_LANES; // wr is a multiple of 4: the piece never wraps
-        at[0] = piece.x;
-        at[RCX_LANES] = piece.y;
-        at[2 * RCX_LANES] = piece.z;
-        at[3 * RCX_LANES] = piece.w;
+        u32* at = ring + (wr % RCX_RING_DW) * stride; // wr is a multiple of 4: the piece never wraps
+        at[0] = piece.x;                               // (lanes sharing a column store identical values)
+        at[stride] = piece.y;
+        at[2 * stride] = piece.z;
+        at[3 * stride] = piece.w;
         wr += 4;
     }
     RCX_DEV u32 ring_get()
     {
-        const u32 v = ring[(rd % RCX_RING_DW) * RCX_LANES];
+        const u32 v = ring[(rd % RCX_RING_DW) * stride];
         rd += 1;
         return v;
     }
 
     // cpprcoder.h:877-896 + :859-870.  `s` points at the block's stream (any alignment),
     // which must be at least 8 bytes long.  Returns the declared size.
-    RCX_DEV u32 begin(const u8* s, const u8* stream_end, u32* ring_column)
+    RCX_DEV u32 begin(const u8* s, const u8* stream_end, u32* ring_column, u32 ring_stride = RCX_LANES)
     {
+        stride = ring_stride;
         u32 declared = (u32)s[0] | ((u32)s[1] << 8) | ((u32)s[2] << 16) | ((u32)s[3] << 24);
         low = ((u32)s[4] << 24) | ((u32)s[5] << 16) | ((u32)s[6] << 8) | (u32)s[7];
         range = 0x00FFFFFFu;
@@ -433,14 +435,15 @@ struct DecLane {
         win = (u64)(rcx_bswap(ring_get()) << (8 * skew)) << 32;
         navail8 = 32 - 8 * skew;
         ahead = ring_get();
-        peek = ring[(rd % RCX_RING_DW) * RCX_LANES];
+        peek = ring[(rd % RCX_RING_DW) * stride];
         short_at = 0xFFFFFFFFu;
         return declared;
     }
 
     // a lane without a block
-    RCX_DEV void idle(const u8* anywhere, u32* ring_column)
+    RCX_DEV void idle(const u8* anywhere, u32* ring_column, u32 ring_stride = RCX_LANES)
     {
+        stride = ring_stride;
         low = 0;
         range = 0x01000000u;
         win = 0;
@@ -488,7 +491,7 @@ struct DecLane {
         navail8 += need ? 32u : 0u;
         ahead = need ? peek : ahead;
         rd += need ? 1u : 0u;
-        peek = ring[(rd % RCX_RING_DW) * RCX_LANES]; // for the next symbol
+        peek = ring[(rd % RCX_RING_DW) * stride]; // for the next symbol
         const u32 k8 = rcx_clz(range) & 0x18u;
         low = (u32)((((u64)low << 32) | (u32)(win >> 32)) << k8 >> 32);
         win <<= k8;

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(RCX_MC_THREADS) void rcx_enc_mc_k(const u8* __restr
 // ===========================================================================
 #define RCX_QUAD_BLOCKS 16
 #define RCX_QUAD_BLOCK_BYTES 1088 /* 16 node sums + 256 counts */
-#define RCX_QUAD_LDS_BYTES (RCX_QUAD_BLOCKS * RCX_QUAD_BLOCK_BYTES + RCX_STAGE * 16 + RCX_RING_DW * RCX_LANES * 4)
+#define RCX_QUAD_LDS_BYTES (RCX_QUAD_BLOCKS * RCX_QUAD_BLOCK_BYTES + RCX_STAGE * 16 + RCX_RING_DW * RCX_QUAD_BLOCKS * 4) /* 20 KiB: two 4-wave workgroups per CU */
 
 __device__ __forceinline__ u32 rcx_quad_sum(u32 x)
 {
@@ -607,7 +607,8 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
     }
     u32 before = 64u * j;
     DivEntry* stage = reinterpret_cast<DivEntry*>(lds + RCX_QUAD_BLOCKS * RCX_QUAD_BLOCK_BYTES);
-    u32* ring_col = reinterpret_cast<u32*>(lds + RCX_QUAD_BLOCKS * RCX_QUAD_BLOCK_BYTES + RCX_STAGE * 16) + lane;
+    // one input ring per block: the 4 lanes of a quad read the same dwords and store identical ones
+    u32* ring_col = reinterpret_cast<u32*>(lds + RCX_QUAD_BLOCKS * RCX_QUAD_BLOCK_BYTES + RCX_STAGE * 16) + quad;
     const u32 m1 = (j & 1u) ? ~0u : 0u, m2 = (j & 2u) ? ~0u : 0u;
 
     DecLane dec;
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
             live = false;
             len = 0;
         } else {
-            const u32 declared = dec.begin(comp + s0, comp + s1, ring_col);
+            const u32 declared = dec.begin(comp + s0, comp + s1, ring_col, RCX_QUAD_BLOCKS);
             if (declared != len) {
                 if (j == 0) rcx_flag(status, RCX_ST_CORRUPT, blk);
                 live = false;
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
             }
         }
     }
-    if (!live) dec.idle(comp, ring_col);
+    if (!live) dec.idle(comp, ring_col, RCX_QUAD_BLOCKS);
 
     const u32 maxlen = rcx_wave_max(len);
     const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
