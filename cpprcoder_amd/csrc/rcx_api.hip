@@ -33,8 +33,8 @@ struct EventPair {
 
 struct rcx_ctx {
     int device = 0;
-    int lanes_per_block = 0; // decode: 0 = pick by block count (default), 8 = octet, 4 = quad, 1 = one lane per block (RCX_LANES_PER_BLOCK)
-    int wide_wg = -1;        // decode workgroups: -1 = pick by block count, 1 = multi-wave, 0 = single-wave (RCX_WIDE_WG)
+    int lanes_per_block = 0; // decode: 0 = default (4, the quad kernel), 8 = octet, 4 = quad, 1 = one lane per block (RCX_LANES_PER_BLOCK)
+    int wide_wg = -1;        // decode workgroups: -1/1 = multi-wave (default), 0 = single-wave (RCX_WIDE_WG)
     int enc_variant = 3;     // encode: 0 = one wave per 64 blocks, 1 = octet, 2 = 4-wave model/coder split, 3 = 5-wave split (RCX_ENC_VARIANT)
     // scratch
     u8* slots = nullptr;
