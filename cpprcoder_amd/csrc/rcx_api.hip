@@ -41,6 +41,8 @@ struct rcx_ctx {
     u64 slots_bytes = 0;
     u32* sizes = nullptr;
     u64 sizes_count = 0;
+    u32* redo = nullptr;        // decode: blocks the quad kernel leaves to the one-lane kernel (corrupt input only)
+    u64 redo_count = 0;
     DivEntry* divtab = nullptr;
     u32 divtab_block = 0;
     u32* status = nullptr;      // device: [flags, first bad block, track0, track1]
@@ -138,6 +140,14 @@ int decode_lanes(const rcx_ctx* c, u64 nblocks)
     return c->lanes_per_block ? c->lanes_per_block : 4;
 }
 
+int ensure_redo(rcx_ctx* c, u64 nblocks)
+{
+    u64 bytes = c->redo_count * sizeof(u32);
+    const int r = grow(reinterpret_cast<void**>(&c->redo), &bytes, (nblocks + 1) * sizeof(u32));
+    c->redo_count = r == RCX_OK ? bytes / sizeof(u32) : 0;
+    return r;
+}
+
 int reserve(rcx_ctx* c, u64 n, u32 block)
 {
     const u64 nblocks = rcx_block_count(n, block);
@@ -150,7 +160,7 @@ int reserve(rcx_ctx* c, u64 n, u32 block)
     r = grow(reinterpret_cast<void**>(&c->sizes), &bytes, (nblocks + 1) * sizeof(u32));
     if (r != RCX_OK) return r;
     c->sizes_count = bytes / sizeof(u32);
-    return RCX_OK;
+    return ensure_redo(c, nblocks);
 }
 
 } // namespace
@@ -227,6 +237,7 @@ void rcx_ctx_destroy(rcx_ctx* c)
     }
     if (c->slots) (void)hipFree(c->slots);
     if (c->sizes) (void)hipFree(c->sizes);
+    if (c->redo) (void)hipFree(c->redo);
     if (c->divtab) (void)hipFree(c->divtab);
     if (c->status) (void)hipFree(c->status);
     if (c->status_host) (void)hipHostFree(c->status_host);
@@ -325,6 +336,8 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
     HIP_TRY(hipSetDevice(c->device));
     int r = ensure_divtab(c, block);
     if (r != RCX_OK) return r;
+    const bool quad = coder == RCX_CODER_ADAPTIVE && decode_lanes(c, nblocks) == 4;
+    if (quad && (r = ensure_redo(c, nblocks)) != RCX_OK) return r; // no-op after rcx_ctx_reserve
     {
         Timed t(c, s, RCX_T_DECODE);
         if (coder == RCX_CODER_STATIC) {
@@ -337,11 +350,11 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
                 const u32 grid = (u32)((nblocks + per_wg - 1) / per_wg);
                 hipLaunchKernelGGL(rcx_dec_quad_k<RCX_QUAD_DEC_WAVES>, dim3(grid), dim3(64 * RCX_QUAD_DEC_WAVES), 0, s,
                                    static_cast<const u8*>(d_comp), d_offsets, nblocks, block, n, static_cast<u8*>(d_dst), c->divtab,
-                                   c->status);
+                                   c->status, c->redo);
             } else {
                 const u32 grid = (u32)((nblocks + RCX_QUAD_BLOCKS - 1) / RCX_QUAD_BLOCKS);
                 hipLaunchKernelGGL(rcx_dec_quad_k<1>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
-                                   block, n, static_cast<u8*>(d_dst), c->divtab, c->status);
+                                   block, n, static_cast<u8*>(d_dst), c->divtab, c->status, c->redo);
             }
         } else if (decode_lanes(c, nblocks) == 8) {
             if (wide_workgroups(c, nblocks)) {
@@ -358,8 +371,18 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
         } else {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_dec_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets,
-                               nblocks, block, n, static_cast<u8*>(d_dst), c->divtab, c->status, static_cast<u32*>(nullptr));
+                               nblocks, block, n, static_cast<u8*>(d_dst), c->divtab, c->status, static_cast<u32*>(nullptr),
+                               static_cast<const u32*>(nullptr));
         }
+    }
+    if (quad) {
+        // Blocks whose stream asked for a symbol past the table (corrupt input) were marked, not decoded, by
+        // the quad kernel: the one-lane kernel, which has the reference's fall-through for that case, decodes
+        // them again.  On valid input nothing is marked and every wave of this launch returns at once.
+        const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
+        hipLaunchKernelGGL(rcx_dec_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets,
+                           nblocks, block, n, static_cast<u8*>(d_dst), c->divtab, c->status, static_cast<u32*>(nullptr),
+                           static_cast<const u32*>(c->redo));
     }
     return hipGetLastError() == hipSuccess ? RCX_OK : RCX_E_HIP;
 }
@@ -560,7 +583,7 @@ int rcx_stream_decode(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
     HIP_TRY(hipMemcpy(c->h_in, comp, comp_size, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->h_off, offs, sizeof(offs), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(rcx_dec_adaptive_k<true>, dim3(1), dim3(64), 0, nullptr, c->h_in, c->h_off, (u64)1, block, count, c->h_out,
-                       c->divtab, c->status, c->status + 2);
+                       c->divtab, c->status, c->status + 2, static_cast<const u32*>(nullptr));
     if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
     HIP_TRY(hipMemcpy(c->status_host, c->status, 4 * sizeof(u32), hipMemcpyDeviceToHost));
     const u32 short_at = c->status_host[2];

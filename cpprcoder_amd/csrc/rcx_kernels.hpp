@@ -198,18 +198,25 @@ __global__ __launch_bounds__(256) void rcx_scatter_k(const u8* __restrict__ slot
 #if defined(RCX_STAMP_DEC)
 static __device__ unsigned long long rcx_dec_stamp_out[8];
 #endif
+// `only` != nullptr: decode just the blocks with only[blk] != 0 (the others are left alone).
 // STREAM = the single-stream entry point: one block whose symbol count n the host took from
 // the header (max(declared,1) clipped to the sink); track[0] = first symbol whose normalize
 // ran out of input, or 0xFFFFFFFF.
 template <bool STREAM>
 __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ comp, const u64* __restrict__ offsets, u64 nblocks,
                                                          u32 block, u64 n, u8* __restrict__ dst,
-                                                         const DivEntry* __restrict__ divtab, u32* status, u32* track)
+                                                         const DivEntry* __restrict__ divtab, u32* status, u32* track,
+                                                         const u32* __restrict__ only)
 {
     __shared__ U4 lds[RCX_DEC_LDS_U4];
     const u32 lane = threadIdx.x;
     const u64 blk = (u64)blockIdx.x * RCX_LANES + lane;
     bool live = blk < nblocks;
+    // second pass behind rcx_dec_quad_k: only the blocks it marked (none, on valid input)
+    if (only) {
+        live = live && only[blk] != 0;
+        if (!__any(live)) return;
+    }
     const u64 at = live ? blk * (u64)block : 0;
     u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
 

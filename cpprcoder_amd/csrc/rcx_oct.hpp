@@ -547,21 +547,58 @@ __global__ __launch_bounds__(RCX_MC_THREADS) void rcx_enc_mc_k(const u8* __restr
 
 // ===========================================================================
 // Decode, 4 lanes per block ("quad"): 16 blocks per wave, 1024 waves for 1 GiB of 64 KiB
-// blocks = one wave per SIMD.  Same scheme as the octet decoder with a 16 x 16 split of the
-// alphabet: lane j owns the node sums 4j..4j+3 (16 symbols each, fixed LDS address) and keeps
-// `before` = the sum of the nodes of lanes < j; round 1 finds the node (each lane tests its 4),
-// round 2 the symbol among the node's 16 (each lane reads 4 counts, one ds_read_b128).
-// An instruction costs a SIMD 4 cycles whether it serves 8 or 16 blocks, so halving the lanes
-// per block halves the machine-wide instruction work of the octet kernel.
+// blocks = one wave per SIMD.  An instruction costs a SIMD 4 cycles whether it serves 8 or 16
+// blocks and a lone wave hides no latency, so the kernel is written for the fewest
+// instructions per symbol and for work between the one dependent LDS read and its use.
+//
+// Model (cpprcoder.h:1094-1243): the alphabet is split 16 nodes x 16 symbols.  Lane j of the
+// block's quad keeps in REGISTERS S0..S4 = the counts of all symbols below node 4j, 4j+1, ...,
+// 4j+4 (absolute cumulative sums; S4 of the last lane is the total); the 256 counts live in
+// LDS, node n as 64 contiguous bytes of which lane j reads counts 4j..4j+3 (one ds_read_b128).
+//
+// find() (cpprcoder.h:1220-1242) in the scaled domain (see DecLane), without selects:
+//   x_k = low - S_k*t wraps past zero exactly for the thresholds above low, so
+//     * the number of borrows, summed over the quad, is 16 - node,
+//     * the unsigned minimum of the x_k over the quad is low - cum(node)*t;
+//   round 2 is the same over the node's 16 counts, and with m = the unsigned maximum of the
+//   wrapped x (the smallest threshold above) the new range count*t is  min - m  (mod 2^32):
+//   cum(c+1)*t - cum(c)*t, no multiply, no select of the count.
+// A target at or past the total (corrupt input only) is detected, not decoded: the block is marked
+// in `redo` and decoded again by rcx_dec_adaptive_k, which has the reference's fall-through.
+//
+// Input: no bit window.  The position in the stream is a bit offset `bp8`; the two ring dwords
+// around it are read right after each renormalisation (for the NEXT symbol, so their latency is
+// never waited for) and the next four bytes are one v_alignbit + one byte swap away.
 // ===========================================================================
 #define RCX_QUAD_BLOCKS 16
-#define RCX_QUAD_BLOCK_BYTES 1088 /* 16 node sums + 256 counts */
-#define RCX_QUAD_LDS_BYTES (RCX_QUAD_BLOCKS * RCX_QUAD_BLOCK_BYTES + RCX_STAGE * 16 + RCX_RING_DW * RCX_QUAD_BLOCKS * 4) /* 20 KiB: two 4-wave workgroups per CU */
+#define RCX_QUAD_BLOCK_BYTES 1088 /* 64 bytes of skew (block 0's hold ring slot 32) + 256 counts */
+#define RCX_QUAD_RING_BYTES (RCX_RING_DW * RCX_QUAD_BLOCKS * 4)
+#define RCX_QUAD_LDS_BYTES (RCX_STAGE * 16 + RCX_QUAD_RING_BYTES + RCX_QUAD_BLOCKS * RCX_QUAD_BLOCK_BYTES) /* 20 KiB: two 4-wave workgroups per CU */
+
+// divisor entry as the quad decoder stages it: the 64-bit addend is read as a register pair
+struct alignas(16) DivQ {
+    u32 mul, st; // st = total << 5 | shift
+    u64 add;
+};
 
 __device__ __forceinline__ u32 rcx_quad_sum(u32 x)
 {
     x += rcx_dpp<0xB1>(x); // quad_perm [1,0,3,2]
     x += rcx_dpp<0x4E>(x); // quad_perm [2,3,0,1]
+    return x;
+}
+__device__ __forceinline__ u32 rcx_umin(u32 a, u32 b) { return a < b ? a : b; }
+__device__ __forceinline__ u32 rcx_umax(u32 a, u32 b) { return a > b ? a : b; }
+__device__ __forceinline__ u32 rcx_quad_min(u32 x)
+{
+    x = rcx_umin(x, rcx_dpp<0xB1>(x));
+    x = rcx_umin(x, rcx_dpp<0x4E>(x));
+    return x;
+}
+__device__ __forceinline__ u32 rcx_quad_or(u32 x)
+{
+    x |= rcx_dpp<0xB1>(x);
+    x |= rcx_dpp<0x4E>(x);
     return x;
 }
 __device__ __forceinline__ u32 rcx_quad_excl_scan(u32 x, u32 m1, u32 m2)
@@ -574,14 +611,113 @@ __device__ __forceinline__ u32 rcx_quad_excl_scan(u32 x, u32 m1, u32 m2)
     return pre;
 }
 
+// The compressed stream of one block as its quad reads it (all 4 lanes hold the same state).
+// Ring: dword d of the stream (counted from `origin`, the 16-byte aligned address at or below
+// the first payload byte) lives in slot d % 32 of the block's column; slot 32 repeats slot 0 so
+// that the pair (d, d+1) is always one ds_read2_b32.  Topped up every 16 symbols (at most
+// 12 dwords are consumed in that time) with 16-byte loads issued one top-up ahead.
+struct QuadInput {
+    u32 low, range;
+    u32 bp8;        // bits of the stream consumed, counted from `origin`
+    u32 w0, w1;     // ring dwords (bp8 >> 5) and (bp8 >> 5) + 1, raw (memory order)
+    u32* col;       // this block's ring column: slot s at col[s * RCX_QUAD_BLOCKS]
+    u32 wr;         // dwords written to the ring so far
+    const u8* origin;
+    const u8* end;  // one past the block's stream
+    u32 body8;      // bit offset of the first payload byte (after the 8 header bytes)
+    U4 pend0, pend1, pend2, pend3;
+    u32 npend;
+
+    __device__ __forceinline__ U4 load16(const u8* p) const
+    {
+        U4 z;
+        z.x = z.y = z.z = z.w = 0;
+        return p < end ? *reinterpret_cast<const U4*>(p) : z; // see DecLane::load16
+    }
+    __device__ __forceinline__ void ring_put(const U4& piece)
+    {
+        const u32 slot = wr % RCX_RING_DW; // a multiple of 4: the piece never wraps
+        u32* at = col + slot * RCX_QUAD_BLOCKS;
+        at[0] = piece.x; // (the 4 lanes of the quad store identical values)
+        at[RCX_QUAD_BLOCKS] = piece.y;
+        at[2 * RCX_QUAD_BLOCKS] = piece.z;
+        at[3 * RCX_QUAD_BLOCKS] = piece.w;
+        if (slot == 0) col[RCX_RING_DW * RCX_QUAD_BLOCKS] = piece.x;
+        wr += 4;
+    }
+    __device__ __forceinline__ void fetch_pair()
+    {
+        const u32* at = col + ((bp8 >> 5) % RCX_RING_DW) * RCX_QUAD_BLOCKS;
+        w0 = at[0];
+        w1 = at[RCX_QUAD_BLOCKS];
+    }
+    // cpprcoder.h:877-896 + :859-870; `s` must hold at least 8 bytes.  Returns the declared size.
+    __device__ __forceinline__ u32 begin(const u8* s, const u8* stream_end, u32* column)
+    {
+        const u32 declared = (u32)s[0] | ((u32)s[1] << 8) | ((u32)s[2] << 16) | ((u32)s[3] << 24);
+        low = ((u32)s[4] << 24) | ((u32)s[5] << 16) | ((u32)s[6] << 8) | (u32)s[7];
+        range = 0x00FFFFFFu;
+        end = stream_end;
+        col = column;
+        const u8* body = s + 8;
+        origin = body - ((uintptr_t)body & 15);
+        wr = 0;
+        for (u32 r = 0; r < 6; ++r) ring_put(load16(origin + 16 * r)); // prologue: 24 dwords, synchronously
+        npend = 0;
+        body8 = 8u * (u32)(body - origin);
+        bp8 = body8;
+        fetch_pair();
+        return declared;
+    }
+    __device__ __forceinline__ void idle(const u8* anywhere, u32* column)
+    {
+        low = 0;
+        range = 0x01000000u;
+        col = column;
+        origin = end = anywhere;
+        wr = 0;
+        npend = 0;
+        body8 = bp8 = 0;
+        w0 = w1 = 0;
+    }
+    // every 16 symbols: the pieces requested last time go into the ring, then as many new ones as
+    // fit are requested (slots [bp8 >> 5, wr) are unread)
+    __device__ __forceinline__ void topup()
+    {
+        if (npend > 0) ring_put(pend0);
+        if (npend > 1) ring_put(pend1);
+        if (npend > 2) ring_put(pend2);
+        if (npend > 3) ring_put(pend3);
+        npend = 0;
+        const u32 rd = bp8 >> 5;
+        u32 planned = wr;
+        if (planned + 4 - rd <= RCX_RING_DW) { pend0 = load16(origin + 4 * (size_t)planned); planned += 4; npend = 1; }
+        if (planned + 4 - rd <= RCX_RING_DW) { pend1 = load16(origin + 4 * (size_t)planned); planned += 4; npend = 2; }
+        if (planned + 4 - rd <= RCX_RING_DW) { pend2 = load16(origin + 4 * (size_t)planned); planned += 4; npend = 3; }
+        if (planned + 4 - rd <= RCX_RING_DW) { pend3 = load16(origin + 4 * (size_t)planned); planned += 4; npend = 4; }
+    }
+    // stream bytes consumed so far, header included (cpprcoder.h:901-903)
+    __device__ __forceinline__ u64 taken() const { return 8 + (u64)((bp8 - body8) >> 3); }
+    // cpprcoder.h:926-940
+    __device__ __forceinline__ void pull()
+    {
+        const u32 next4 = rcx_bswap(rcx_funnel_shr(w1, w0, bp8)); // the 4 bytes at bp8, first one on top
+        const u32 k8 = rcx_clz(range) & 0x18u;
+        low = (u32)((((u64)low << 32) | next4) << k8 >> 32);
+        range <<= k8;
+        bp8 += k8;
+        fetch_pair(); // for the next symbol
+    }
+};
+
 // A workgroup is WAVES independent waves: with few blocks, 4 waves per workgroup land one on each SIMD of a
-// CU (single-wave workgroups do not: measured 25.4 -> 19.3 ms per GiB at 16384 blocks); with many blocks
-// single-wave workgroups pack more waves onto a CU.
+// CU (single-wave workgroups do not: measured 25.4 -> 19.3 ms per GiB at 16384 blocks).
 #define RCX_QUAD_DEC_WAVES 4
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restrict__ comp, const u64* __restrict__ offsets,
                                                              u64 nblocks, u32 block, u64 n, u8* __restrict__ dst,
-                                                             const DivEntry* __restrict__ divtab, u32* status)
+                                                             const DivEntry* __restrict__ divtab, u32* status,
+                                                             u32* __restrict__ redo)
 {
     __shared__ __attribute__((aligned(16))) u8 lds_all[WAVES * RCX_QUAD_LDS_BYTES];
     const u32 lane = threadIdx.x & 63u;
@@ -593,25 +729,22 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
     const u64 at = live ? blk * (u64)block : 0;
     u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
 
+    DivQ* stage = reinterpret_cast<DivQ*>(lds);
+    u32* ring_col = reinterpret_cast<u32*>(lds + RCX_STAGE * 16) + quad; // slot 32 = the skew bytes of block 0
+    u8* mine = lds + RCX_STAGE * 16 + RCX_QUAD_RING_BYTES + quad * RCX_QUAD_BLOCK_BYTES;
+    U4* leaves = reinterpret_cast<U4*>(mine + 64) + j; // node n: leaves[n * 4]
     // model: cpprcoder.h:1094-1132, every count 1
-    u8* mine = lds + quad * RCX_QUAD_BLOCK_BYTES;
-    U4* nodes = reinterpret_cast<U4*>(mine) + j;
-    U4* leaves = reinterpret_cast<U4*>(mine + 64);
     {
         U4 v;
-        v.x = v.y = v.z = v.w = 16;
-        *nodes = v;
         v.x = v.y = v.z = v.w = 1;
 #pragma unroll
-        for (u32 q = 0; q < 16; ++q) leaves[q * 4 + j] = v;
+        for (u32 q = 0; q < 16; ++q) leaves[q * 4] = v;
     }
-    u32 before = 64u * j;
-    DivEntry* stage = reinterpret_cast<DivEntry*>(lds + RCX_QUAD_BLOCKS * RCX_QUAD_BLOCK_BYTES);
-    // one input ring per block: the 4 lanes of a quad read the same dwords and store identical ones
-    u32* ring_col = reinterpret_cast<u32*>(lds + RCX_QUAD_BLOCKS * RCX_QUAD_BLOCK_BYTES + RCX_STAGE * 16) + quad;
+    u32 S0 = 64u * j, S1 = S0 + 16, S2 = S0 + 32, S3 = S0 + 48, S4 = S0 + 64;
+    const u32 T0 = 4u * j;
     const u32 m1 = (j & 1u) ? ~0u : 0u, m2 = (j & 2u) ? ~0u : 0u;
 
-    DecLane dec;
+    QuadInput in;
     u64 stream_len = 0;
     if (live) {
         const u64 s0 = offsets[blk], s1 = offsets[blk + 1];
@@ -621,7 +754,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
             live = false;
             len = 0;
         } else {
-            const u32 declared = dec.begin(comp + s0, comp + s1, ring_col, RCX_QUAD_BLOCKS);
+            const u32 declared = in.begin(comp + s0, comp + s1, ring_col);
             if (declared != len) {
                 if (j == 0) rcx_flag(status, RCX_ST_CORRUPT, blk);
                 live = false;
@@ -629,65 +762,89 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
             }
         }
     }
-    if (!live) dec.idle(comp, ring_col, RCX_QUAD_BLOCKS);
+    if (!live) in.idle(comp, ring_col);
 
     const u32 maxlen = rcx_wave_max(len);
     const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
     u8* out = dst + at;
     const bool leader = live && j == 0;
 
-    // One symbol; all comparisons in the scaled domain (see DecLane).
-#define RCX_QUAD_DEC_SYMBOL(K, SYM)                                                                        \
+    // One symbol.  CONTRIB receives the symbol in the owning lane and 0 in the quad's other lanes.
+    // A target at or past the total -- possible only on a corrupt stream -- is not decoded here: the
+    // top threshold is taken as above `low` whatever it is (so the node index stays inside the table),
+    // the block is marked in `redo`, and rcx_dec_adaptive_k decodes marked blocks again with the
+    // reference's fall-through (cpprcoder.h:1220-1242).
+    bool past_total = false;
+    const bool last = j == 3;
+    const u32 T2 = T0 + 2, T3 = T0 + 3, T4 = T0 + 4;
+#define RCX_QUAD_DEC_SYMBOL(K, CONTRIB)                                                                    \
     {                                                                                                      \
-        const U4 g_ = *nodes;                                                                              \
-        dec.pull();                                                                                        \
-        const DivEntry k_ = (K);                                                                           \
-        const u32 t_ = rcx_div(dec.range, k_);                                                             \
-        const u32 top_ = rcx_mul24(k_.total, t_);                                                          \
+        in.pull();                                                                                         \
+        const DivQ k_ = (K);                                                                               \
+        const u32 t_ = (u32)(((u64)in.range * k_.mul + k_.add) >> 32) >> (k_.st & 31u); /* :904 */          \
         /* round 1: which of the 16 nodes */                                                               \
-        const u32 d_ = dec.low - rcx_mul24(before, t_);                                                    \
-        const u32 s2_ = g_.x + g_.y, s3_ = s2_ + g_.z, s4_ = s3_ + g_.w;                                   \
-        const u32 a_ = rcx_mul24(g_.x, t_), b_ = rcx_mul24(s2_, t_), c_ = rcx_mul24(s3_, t_);              \
-        const u32 e_ = rcx_mul24(s4_, t_);                                                                 \
-        u32 p_ = 0, base_ = 0;                                                                             \
-        if (d_ >= a_) { p_ = 1; base_ = a_; }                                                              \
-        if (d_ >= b_) { p_ = 2; base_ = b_; }                                                              \
-        if (d_ >= c_) { p_ = 3; base_ = c_; }                                                              \
-        const bool own1_ = d_ < e_;                                                                        \
-        const u32 node_ = rcx_quad_sum(own1_ ? 4u * j + p_ : 0u);                                          \
-        const u32 rem_ = rcx_quad_sum(own1_ ? d_ - base_ : 0u);                                            \
+        const u32 x0_ = in.low - rcx_mul24(S0, t_);                                                        \
+        u32 x1_, x2_, x3_;                                                                                 \
+        u32 above_ = __builtin_usub_overflow(in.low, rcx_mul24(S1, t_), &x1_) ? 1u : 0u;                   \
+        above_ += __builtin_usub_overflow(in.low, rcx_mul24(S2, t_), &x2_) ? 1u : 0u;                      \
+        above_ += __builtin_usub_overflow(in.low, rcx_mul24(S3, t_), &x3_) ? 1u : 0u;                      \
+        const bool below4_ = in.low < rcx_mul24(S4, t_);                                                   \
+        past_total |= !below4_; /* meaningful in the last lane, whose S4 is the total */                   \
+        above_ += (below4_ || last) ? 1u : 0u;                                                             \
+        above_ = rcx_quad_sum(above_);                                                                     \
+        const u32 rem_ = rcx_quad_min(rcx_umin(rcx_umin(x0_, x1_), rcx_umin(x2_, x3_)));                   \
+        const u32 node_ = 16u - above_;                                                                    \
         /* round 2: which of the node's 16 symbols */                                                      \
-        U4* lg_ = leaves + node_ * 4 + j;                                                                  \
+        U4* lg_ = leaves + node_ * 4;                                                                      \
         const U4 l_ = *lg_;                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        /* meanwhile cpprcoder.h:1134-1177: +1 on every cumulative sum above the node.  Five compares    */ \
+        /* into five mask registers, then five add-with-carry: no compare result is used right away.     */ \
+        {                                                                                                  \
+            u64 c0_, c1_, c2_, c3_, c4_;                                                                   \
+            asm volatile("v_cmp_lt_u32_e64 %[c0], %[n], %[t0]\n\t"                                         \
+                         "v_cmp_le_u32_e64 %[c1], %[n], %[t0]\n\t"                                         \
+                         "v_cmp_lt_u32_e64 %[c2], %[n], %[t2]\n\t"                                         \
+                         "v_cmp_lt_u32_e64 %[c3], %[n], %[t3]\n\t"                                         \
+                         "v_cmp_lt_u32_e64 %[c4], %[n], %[t4]\n\t"                                         \
+                         "v_addc_co_u32_e64 %[s0], %[c0], 0, %[s0], %[c0]\n\t"                             \
+                         "v_addc_co_u32_e64 %[s1], %[c1], 0, %[s1], %[c1]\n\t"                             \
+                         "v_addc_co_u32_e64 %[s2], %[c2], 0, %[s2], %[c2]\n\t"                             \
+                         "v_addc_co_u32_e64 %[s3], %[c3], 0, %[s3], %[c3]\n\t"                             \
+                         "v_addc_co_u32_e64 %[s4], %[c4], 0, %[s4], %[c4]"                                 \
+                         : [s0] "+v"(S0), [s1] "+v"(S1), [s2] "+v"(S2), [s3] "+v"(S3), [s4] "+v"(S4),      \
+                           [c0] "=&s"(c0_), [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_),             \
+                           [c4] "=&s"(c4_)                                                                 \
+                         : [n] "v"(node_), [t0] "v"(T0), [t2] "v"(T2), [t3] "v"(T3), [t4] "v"(T4));        \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
         const u32 t2_ = l_.x + l_.y, t3_ = t2_ + l_.z, t4_ = t3_ + l_.w;                                   \
         const u32 ex_ = rcx_quad_excl_scan(t4_, m1, m2);                                                   \
         const u32 d2_ = rem_ - rcx_mul24(ex_, t_);                                                         \
-        const u32 a2_ = rcx_mul24(l_.x, t_), b2_ = rcx_mul24(t2_, t_), c2_ = rcx_mul24(t3_, t_);           \
-        const u32 e2_ = rcx_mul24(t4_, t_);                                                                \
-        u32 p2_ = 0, base2_ = 0, hit_ = l_.x;                                                              \
-        if (d2_ >= a2_) { p2_ = 1; base2_ = a2_; hit_ = l_.y; }                                            \
-        if (d2_ >= b2_) { p2_ = 2; base2_ = b2_; hit_ = l_.z; }                                            \
-        if (d2_ >= c2_) { p2_ = 3; base2_ = c2_; hit_ = l_.w; }                                            \
-        const bool own2_ = d2_ < e2_;                                                                      \
-        u32 low_ = rcx_quad_sum(own2_ ? d2_ - base2_ : 0u);                                                \
-        const u32 range_ = rcx_quad_sum(own2_ ? rcx_mul24(hit_, t_) : 0u);                                 \
-        const u32 lp_ = rcx_quad_sum(own2_ ? 4u * j + p2_ : 0u);                                           \
-        /* target >= total: the reference's find() falls through to code 0 / count = total */              \
-        if (dec.low >= top_) low_ = dec.low - top_;                                                        \
-        dec.low = low_;                                                                                    \
-        dec.range = range_;                                                                                \
-        /* cpprcoder.h:1134-1177, +1 on the symbol and on its node */                                      \
-        rcx_lds_add(reinterpret_cast<u32*>(lg_) + p2_, own2_ ? 1u : 0u);                                   \
-        const u32 grp_ = node_ >> 2;                                                                       \
-        rcx_lds_add(reinterpret_cast<u32*>(nodes) + (node_ & 3u), j == grp_ ? 1u : 0u);                    \
-        before += j > grp_ ? 1u : 0u;                                                                      \
-        (SYM) = node_ * 16 + lp_;                                                                          \
+        u32 xa_, xb_, xc_, xe_;                                                                            \
+        u32 above2_ = __builtin_usub_overflow(d2_, rcx_mul24(l_.x, t_), &xa_) ? 1u : 0u;                   \
+        above2_ += __builtin_usub_overflow(d2_, rcx_mul24(t2_, t_), &xb_) ? 1u : 0u;                       \
+        above2_ += __builtin_usub_overflow(d2_, rcx_mul24(t3_, t_), &xc_) ? 1u : 0u;                       \
+        const bool own_ = __builtin_usub_overflow(d2_, rcx_mul24(t4_, t_), &xe_);                          \
+        const u32 lo_ = rcx_umin(rcx_umin(d2_, xa_), rcx_umin(xb_, xc_));                                  \
+        const u32 hi_ = rcx_umax(rcx_umax(xa_, xb_), rcx_umax(xc_, xe_));                                  \
+        in.low = rcx_quad_min(lo_);                       /* :906 */                                       \
+        in.range = rcx_quad_sum(own_ ? lo_ - hi_ : 0u);   /* :907 */                                       \
+        const u32 p_ = 3u - above2_;                                                                       \
+        rcx_lds_add(reinterpret_cast<u32*>(lg_) + p_, own_ ? 1u : 0u); /* :916 */                           \
+        (CONTRIB) = own_ ? node_ * 16u + T0 + p_ : 0u;                                                     \
     }
 
     DivEntry ahead = divtab[lane];
     if (full) {
         for (u32 i0 = 0; i0 < maxlen; i0 += RCX_STAGE) {
-            stage[lane] = ahead;
+            {
+                DivQ q;
+                q.mul = ahead.mul;
+                q.st = (ahead.total << 5) | ahead.shift;
+                q.add = ahead.add;
+                stage[lane] = q;
+            }
             ahead = divtab[i0 + RCX_STAGE + lane];
             const u32 jend = (maxlen - i0) < RCX_STAGE ? (maxlen - i0) : RCX_STAGE;
             // 64 decoded bytes are held and stored as four back-to-back 16-byte stores, so that L2 sees whole
@@ -695,21 +852,21 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
             U4 held[4];
             for (u32 j0 = 0; j0 < jend; j0 += 16) {
                 u32 word[4] = {0, 0, 0, 0};
-                dec.topup();
-                DivEntry k_next = stage[j0];
+                in.topup();
+                DivQ k_next = stage[j0];
 #pragma unroll
                 for (u32 s = 0; s < 16; ++s) {
-                    u32 sym;
-                    const DivEntry kk = k_next;
+                    u32 part;
+                    const DivQ kk = k_next;
                     if (s + 1 < 16) k_next = stage[j0 + s + 1];
-                    RCX_QUAD_DEC_SYMBOL(kk, sym);
-                    word[s >> 2] |= sym << (8 * (s & 3));
+                    RCX_QUAD_DEC_SYMBOL(kk, part);
+                    word[s >> 2] |= part << (8 * (s & 3));
                 }
                 U4 o;
-                o.x = word[0];
-                o.y = word[1];
-                o.z = word[2];
-                o.w = word[3];
+                o.x = rcx_quad_or(word[0]);
+                o.y = rcx_quad_or(word[1]);
+                o.z = rcx_quad_or(word[2]);
+                o.w = rcx_quad_or(word[3]);
                 if (j0 == 0) held[0] = o;
                 else if (j0 == 16) held[1] = o;
                 else if (j0 == 32) held[2] = o;
@@ -725,23 +882,33 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
         }
     } else {
         for (u32 i0 = 0; i0 < maxlen; i0 += RCX_STAGE) {
-            stage[lane] = ahead;
+            {
+                DivQ q;
+                q.mul = ahead.mul;
+                q.st = (ahead.total << 5) | ahead.shift;
+                q.add = ahead.add;
+                stage[lane] = q;
+            }
             ahead = divtab[i0 + RCX_STAGE + lane];
             const u32 jend = (maxlen - i0) < RCX_STAGE ? (maxlen - i0) : RCX_STAGE;
             for (u32 s = 0; s < jend; ++s) {
                 const u32 i = i0 + s;
-                const DivEntry k = stage[s];
-                if ((s & 15u) == 0) dec.topup();
-                if (i < len) {
-                    u32 sym;
-                    RCX_QUAD_DEC_SYMBOL(k, sym);
-                    if (leader) out[i] = (u8)sym;
+                const DivQ k = stage[s];
+                if ((s & 15u) == 0) in.topup();
+                if (i < len) { // the 4 lanes of a quad agree
+                    u32 part;
+                    RCX_QUAD_DEC_SYMBOL(k, part);
+                    part = rcx_quad_or(part);
+                    if (leader) out[i] = (u8)part;
                 }
             }
         }
     }
 #undef RCX_QUAD_DEC_SYMBOL
-    if (leader && dec.taken() > stream_len) rcx_flag(status, RCX_ST_CORRUPT, blk);
+    // a marked block is judged (truncated or not) by the kernel that decodes it again
+    const bool marked = rcx_quad_or((last && live && past_total) ? 1u : 0u) != 0;
+    if (leader && !marked && in.taken() > stream_len) rcx_flag(status, RCX_ST_CORRUPT, blk);
+    if (last && blk < nblocks) redo[blk] = marked ? 1u : 0u;
 }
 
 // ===========================================================================

@@ -177,6 +177,47 @@ def test_errors_are_reported_not_fatal(ctx, oracle):
         ctx.encode_blocks_device(src, (1 << 20) + 16, dst, offs)
 
 
+def test_corrupt_payload_decodes_like_the_reference(ctx, oracle):
+    """A damaged stream still decodes to SOME bytes in the reference (cpprcoder.h:900-917: no check
+    beyond running out of input), including find()'s fall-through for a target at or past the
+    total (cpprcoder.h:1220-1242).  The block entry points give the same bytes: the 4-lane kernel
+    marks such blocks and the one-lane kernel decodes them again.  Every damaged stream is followed
+    by random bytes so that neither decoder runs out of input."""
+    block, nblocks = 4096, 96
+    data = workloads.zipf(block * nblocks, 21)
+    slots, sizes = oracle.encode_blocks(data, block, threads=8)
+    rs = np.random.RandomState(5)
+    pad = 3 * block
+    big = np.zeros((nblocks, slots.shape[1] + pad), np.uint8)
+    big_sizes = sizes.copy()
+    hit = set()
+    for b in range(nblocks):
+        z = int(sizes[b])
+        big[b, :z] = slots[b, :z]
+        if b % 3:
+            continue
+        hit.add(b)
+        big[b, z: z + pad] = rs.randint(0, 256, pad)
+        big_sizes[b] = z + pad
+        if b % 2 == 0:
+            # the first renormalisation shifts in bytes 5..8: low >= 0xFFFFFF00 = 256 * (0xFFFFFF00 / 256),
+            # the total's threshold -> the very first symbol is past the table
+            big[b, 5:9] = 0xFF
+        else:
+            for _ in range(4):
+                big[b, int(rs.randint(9, z))] ^= int(rs.randint(1, 256))
+    want, ok = oracle.decode_blocks(big, big_sizes, block, len(data), threads=8)
+    assert ok
+    payload, offsets = oracle.compact(big, big_sizes)
+    back, st, _ = gpu_decode(ctx, payload, offsets, len(data), block)
+    assert st == 0
+    for b in range(nblocks):
+        assert np.array_equal(back[b * block:(b + 1) * block], want[b * block:(b + 1) * block]), f"block {b}"
+        if b not in hit:
+            assert np.array_equal(back[b * block:(b + 1) * block], data[b * block:(b + 1) * block])
+    assert not np.array_equal(want, data)
+
+
 def test_single_stream_semantics(ctx, oracle, golden):
     """rcx_stream_encode / rcx_stream_decode == the reference's initialize+encode / initialize+decode
     on a MemoryStream of the given capacity (cpprcoder.h:678-720, 859-924, 1047-1054)."""
