@@ -547,33 +547,42 @@ __global__ __launch_bounds__(RCX_MC_THREADS) void rcx_enc_mc_k(const u8* __restr
 
 // ===========================================================================
 // Decode, 4 lanes per block ("quad"): 16 blocks per wave, 1024 waves for 1 GiB of 64 KiB
-// blocks = one wave per SIMD.  An instruction costs a SIMD 4 cycles whether it serves 8 or 16
-// blocks and a lone wave hides no latency, so the kernel is written for the fewest
-// instructions per symbol and for work between the one dependent LDS read and its use.
+// blocks = one wave per SIMD.  A lone wave issues one instruction -- vector, scalar, s_nop or
+// s_waitcnt alike -- every 4 cycles and hides no latency (tools/diag/ubench.hip), so the kernel is
+// written for the fewest instructions per symbol of any kind, and for work between the one
+// dependent LDS read and its use.
 //
 // Model (cpprcoder.h:1094-1243): the alphabet is split 16 nodes x 16 symbols.  Lane j of the
-// block's quad keeps in REGISTERS S0..S4 = the counts of all symbols below node 4j, 4j+1, ...,
-// 4j+4 (absolute cumulative sums; S4 of the last lane is the total); the 256 counts live in
-// LDS, node n as 64 contiguous bytes of which lane j reads counts 4j..4j+3 (one ds_read_b128).
+// block's quad keeps in REGISTERS U1..U4 = the counts of all symbols below node 4j+1, ..., 4j+4
+// (absolute cumulative sums: the upper bounds of its four nodes; U4 of the last lane is the
+// total); the 256 counts live in LDS, node n as 64 contiguous bytes of which lane j reads counts
+// 4j..4j+3 (one ds_read_b128).
 //
 // find() (cpprcoder.h:1220-1242) in the scaled domain (see DecLane), without selects:
-//   x_k = low - S_k*t wraps past zero exactly for the thresholds above low, so
+//   x_k = low - U_k*t wraps past zero exactly for the bounds above low, so
 //     * the number of borrows, summed over the quad, is 16 - node,
-//     * the unsigned minimum of the x_k over the quad is low - cum(node)*t;
-//   round 2 is the same over the node's 16 counts, and with m = the unsigned maximum of the
-//   wrapped x (the smallest threshold above) the new range count*t is  min - m  (mod 2^32):
-//   cum(c+1)*t - cum(c)*t, no multiply, no select of the count.
-// A target at or past the total (corrupt input only) is detected, not decoded: the block is marked
-// in `redo` and decoded again by rcx_dec_adaptive_k, which has the reference's fall-through.
+//     * the unsigned minimum of low and all x_k over the quad is low - cum(node)*t;
+//   round 2 is the same over the node's 16 counts, and the unsigned maximum of the x over the
+//   quad is the (wrapped) distance to the smallest bound above, so the new range count*t is
+//   min - max (mod 2^32): cum(c+1)*t - cum(c)*t, no multiply, no select of the count.
+// A target at or past the total (corrupt input only) leaves no borrow in round 1 and "node 16",
+// whose counts are a scratch area behind the block's table.  Such a block is detected, not
+// decoded: it is marked in `redo` and decoded again by rcx_dec_adaptive_k, which has the
+// reference's fall-through for that case.
 //
 // Input: no bit window.  The position in the stream is a bit offset `bp8`; the two ring dwords
 // around it are read right after each renormalisation (for the NEXT symbol, so their latency is
 // never waited for) and the next four bytes are one v_alignbit + one byte swap away.
 // ===========================================================================
 #define RCX_QUAD_BLOCKS 16
-#define RCX_QUAD_BLOCK_BYTES 1088 /* 64 bytes of skew (block 0's hold ring slot 32) + 256 counts */
-#define RCX_QUAD_RING_BYTES (RCX_RING_DW * RCX_QUAD_BLOCKS * 4)
-#define RCX_QUAD_LDS_BYTES (RCX_STAGE * 16 + RCX_QUAD_RING_BYTES + RCX_QUAD_BLOCKS * RCX_QUAD_BLOCK_BYTES) /* 20 KiB: two 4-wave workgroups per CU */
+#define RCX_QUAD_STAGE 32 /* divisor entries staged per refill */
+// one block in LDS: 256 counts | 64 scratch bytes ("node 16", and where skipped ring writes go) |
+// ring of 32 dwords | ring slot 32 (repeats slot 0) + 12 spare bytes.  1232 / 4 = 52 (mod 64): the 16
+// blocks of a wave start 4 banks apart.
+#define RCX_QUAD_BLOCK_BYTES 1232
+#define RCX_QUAD_SCRATCH_OFF 1024
+#define RCX_QUAD_RING_OFF 1088
+#define RCX_QUAD_LDS_BYTES (RCX_QUAD_STAGE * 16 + RCX_QUAD_BLOCKS * RCX_QUAD_BLOCK_BYTES) /* 19.75 KiB: two 4-wave workgroups per CU */
 
 // divisor entry as the quad decoder stages it: the 64-bit addend is read as a register pair
 struct alignas(16) DivQ {
@@ -595,6 +604,12 @@ __device__ __forceinline__ u32 rcx_quad_min(u32 x)
     x = rcx_umin(x, rcx_dpp<0x4E>(x));
     return x;
 }
+__device__ __forceinline__ u32 rcx_quad_max(u32 x)
+{
+    x = rcx_umax(x, rcx_dpp<0xB1>(x));
+    x = rcx_umax(x, rcx_dpp<0x4E>(x));
+    return x;
+}
 __device__ __forceinline__ u32 rcx_quad_or(u32 x)
 {
     x |= rcx_dpp<0xB1>(x);
@@ -611,90 +626,94 @@ __device__ __forceinline__ u32 rcx_quad_excl_scan(u32 x, u32 m1, u32 m2)
     return pre;
 }
 
-// The compressed stream of one block as its quad reads it (all 4 lanes hold the same state).
-// Ring: dword d of the stream (counted from `origin`, the 16-byte aligned address at or below
-// the first payload byte) lives in slot d % 32 of the block's column; slot 32 repeats slot 0 so
-// that the pair (d, d+1) is always one ds_read2_b32.  Topped up every 16 symbols (at most
-// 12 dwords are consumed in that time) with 16-byte loads issued one top-up ahead.
+// The compressed stream of one block as its quad reads it (all 4 lanes hold the same state and
+// store the same values).
+// Ring: dword d of the stream (counted from `origin`, the 16-byte aligned address at or below the
+// first payload byte) lives in ring[d % 32]; ring[32] repeats ring[0] so that the pair (d, d+1)
+// is always one ds_read2_b32.  Every 16 symbols (which consume at most 12 dwords) topup() moves
+// the two 16-byte pieces it requested the time before into the ring and requests the next two --
+// unconditionally: a piece the ring has no room for is written to the scratch area instead and
+// asked for again.  A quad that falls behind (more than 8 dwords per 16 symbols: possible, rare)
+// is refilled synchronously on a cold branch.
 struct QuadInput {
     u32 low, range;
     u32 bp8;        // bits of the stream consumed, counted from `origin`
     u32 w0, w1;     // ring dwords (bp8 >> 5) and (bp8 >> 5) + 1, raw (memory order)
-    u32* col;       // this block's ring column: slot s at col[s * RCX_QUAD_BLOCKS]
+    u32* ring;      // this block's ring; ring - 16 is its 64-byte scratch area
     u32 wr;         // dwords written to the ring so far
+    u32 nfit;       // how many of pendA, pendB (requested at the last top-up) the ring has room for
+    U4 pendA, pendB;
     const u8* origin;
-    const u8* end;  // one past the block's stream
+    u32 last_off;   // byte offset from origin of the last 16-byte piece that may be loaded
     u32 body8;      // bit offset of the first payload byte (after the 8 header bytes)
-    U4 pend0, pend1, pend2, pend3;
-    u32 npend;
 
-    __device__ __forceinline__ U4 load16(const u8* p) const
+    // a piece at or past the end of the stream repeats the stream's last piece (never used by a valid
+    // stream; the piece holding the last byte stays inside that byte's page)
+    __device__ __forceinline__ U4 load16(u32 off) const
     {
-        U4 z;
-        z.x = z.y = z.z = z.w = 0;
-        return p < end ? *reinterpret_cast<const U4*>(p) : z; // see DecLane::load16
+        return *reinterpret_cast<const U4*>(origin + (off < last_off ? off : last_off));
     }
-    __device__ __forceinline__ void ring_put(const U4& piece)
+    __device__ __forceinline__ void ring_put(const U4& piece, bool really)
     {
         const u32 slot = wr % RCX_RING_DW; // a multiple of 4: the piece never wraps
-        u32* at = col + slot * RCX_QUAD_BLOCKS;
-        at[0] = piece.x; // (the 4 lanes of the quad store identical values)
-        at[RCX_QUAD_BLOCKS] = piece.y;
-        at[2 * RCX_QUAD_BLOCKS] = piece.z;
-        at[3 * RCX_QUAD_BLOCKS] = piece.w;
-        if (slot == 0) col[RCX_RING_DW * RCX_QUAD_BLOCKS] = piece.x;
-        wr += 4;
+        *reinterpret_cast<U4*>(really ? ring + slot : ring - 16) = piece;
+        ring[really && slot == 0 ? RCX_RING_DW : RCX_RING_DW + 1] = piece.x;
+        wr += really ? 4u : 0u;
     }
     __device__ __forceinline__ void fetch_pair()
     {
-        const u32* at = col + ((bp8 >> 5) % RCX_RING_DW) * RCX_QUAD_BLOCKS;
+        const u32* at = ring + ((bp8 >> 5) % RCX_RING_DW);
         w0 = at[0];
-        w1 = at[RCX_QUAD_BLOCKS];
+        w1 = at[1];
     }
     // cpprcoder.h:877-896 + :859-870; `s` must hold at least 8 bytes.  Returns the declared size.
-    __device__ __forceinline__ u32 begin(const u8* s, const u8* stream_end, u32* column)
+    __device__ __forceinline__ u32 begin(const u8* s, const u8* stream_end, u32* block_ring)
     {
         const u32 declared = (u32)s[0] | ((u32)s[1] << 8) | ((u32)s[2] << 16) | ((u32)s[3] << 24);
         low = ((u32)s[4] << 24) | ((u32)s[5] << 16) | ((u32)s[6] << 8) | (u32)s[7];
         range = 0x00FFFFFFu;
-        end = stream_end;
-        col = column;
+        ring = block_ring;
         const u8* body = s + 8;
         origin = body - ((uintptr_t)body & 15);
+        last_off = (u32)(stream_end - 1 - origin) & ~15u;
         wr = 0;
-        for (u32 r = 0; r < 6; ++r) ring_put(load16(origin + 16 * r)); // prologue: 24 dwords, synchronously
-        npend = 0;
+        for (u32 r = 0; r < 6; ++r) ring_put(load16(16 * r), true); // prologue: 24 dwords, synchronously
+        nfit = 0;
+        pendA.x = pendA.y = pendA.z = pendA.w = 0;
+        pendB = pendA;
         body8 = 8u * (u32)(body - origin);
         bp8 = body8;
         fetch_pair();
         return declared;
     }
-    __device__ __forceinline__ void idle(const u8* anywhere, u32* column)
+    // a lane without a block: reads 16 bytes at the start of the compressed buffer, over and over
+    __device__ __forceinline__ void idle(const u8* anywhere, u32* block_ring)
     {
         low = 0;
         range = 0x01000000u;
-        col = column;
-        origin = end = anywhere;
-        wr = 0;
-        npend = 0;
+        ring = block_ring;
+        origin = anywhere - ((uintptr_t)anywhere & 15);
+        last_off = 0;
+        wr = 24;
+        nfit = 0;
+        pendA.x = pendA.y = pendA.z = pendA.w = 0;
+        pendB = pendA;
         body8 = bp8 = 0;
         w0 = w1 = 0;
     }
-    // every 16 symbols: the pieces requested last time go into the ring, then as many new ones as
-    // fit are requested (slots [bp8 >> 5, wr) are unread)
     __device__ __forceinline__ void topup()
     {
-        if (npend > 0) ring_put(pend0);
-        if (npend > 1) ring_put(pend1);
-        if (npend > 2) ring_put(pend2);
-        if (npend > 3) ring_put(pend3);
-        npend = 0;
-        const u32 rd = bp8 >> 5;
-        u32 planned = wr;
-        if (planned + 4 - rd <= RCX_RING_DW) { pend0 = load16(origin + 4 * (size_t)planned); planned += 4; npend = 1; }
-        if (planned + 4 - rd <= RCX_RING_DW) { pend1 = load16(origin + 4 * (size_t)planned); planned += 4; npend = 2; }
-        if (planned + 4 - rd <= RCX_RING_DW) { pend2 = load16(origin + 4 * (size_t)planned); planned += 4; npend = 3; }
-        if (planned + 4 - rd <= RCX_RING_DW) { pend3 = load16(origin + 4 * (size_t)planned); planned += 4; npend = 4; }
+        ring_put(pendA, nfit >= 1);
+        ring_put(pendB, nfit >= 2);
+        const u32 rd = bp8 >> 5; // ring[rd % 32 ...] are unread
+        if (rcx_any(wr - rd < 14u)) { // the next 16 symbols may need 12 dwords and the pair after them
+            asm volatile("" ::: "memory"); // keep this a branch: taken only on a run of very improbable symbols
+            while (__any(wr - rd <= 20u)) ring_put(load16(4 * wr), wr - rd <= 20u);
+        }
+        const u32 room = (rd + RCX_RING_DW - wr) >> 2;
+        nfit = room < 2u ? room : 2u;
+        pendA = load16(4 * wr);
+        pendB = load16(4 * wr + 16);
     }
     // stream bytes consumed so far, header included (cpprcoder.h:901-903)
     __device__ __forceinline__ u64 taken() const { return 8 + (u64)((bp8 - body8) >> 3); }
@@ -730,18 +749,18 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
     u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
 
     DivQ* stage = reinterpret_cast<DivQ*>(lds);
-    u32* ring_col = reinterpret_cast<u32*>(lds + RCX_STAGE * 16) + quad; // slot 32 = the skew bytes of block 0
-    u8* mine = lds + RCX_STAGE * 16 + RCX_QUAD_RING_BYTES + quad * RCX_QUAD_BLOCK_BYTES;
-    U4* leaves = reinterpret_cast<U4*>(mine + 64) + j; // node n: leaves[n * 4]
+    u8* mine = lds + RCX_QUAD_STAGE * 16 + quad * RCX_QUAD_BLOCK_BYTES;
+    U4* leaves = reinterpret_cast<U4*>(mine) + j; // node n: leaves[n * 4]
+    u32* block_ring = reinterpret_cast<u32*>(mine + RCX_QUAD_RING_OFF);
     // model: cpprcoder.h:1094-1132, every count 1
     {
         U4 v;
         v.x = v.y = v.z = v.w = 1;
 #pragma unroll
-        for (u32 q = 0; q < 16; ++q) leaves[q * 4] = v;
+        for (u32 q = 0; q < 17; ++q) leaves[q * 4] = v; // 16 nodes + the scratch area
     }
-    u32 S0 = 64u * j, S1 = S0 + 16, S2 = S0 + 32, S3 = S0 + 48, S4 = S0 + 64;
-    const u32 T0 = 4u * j;
+    u32 U1 = 64u * j + 16, U2 = U1 + 16, U3 = U1 + 32, U4_ = U1 + 48;
+    const u32 T0 = 4u * j, T1 = T0 + 1, T2 = T0 + 2, T3 = T0 + 3;
     const u32 m1 = (j & 1u) ? ~0u : 0u, m2 = (j & 2u) ? ~0u : 0u;
 
     QuadInput in;
@@ -754,7 +773,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
             live = false;
             len = 0;
         } else {
-            const u32 declared = in.begin(comp + s0, comp + s1, ring_col);
+            const u32 declared = in.begin(comp + s0, comp + s1, block_ring);
             if (declared != len) {
                 if (j == 0) rcx_flag(status, RCX_ST_CORRUPT, blk);
                 live = false;
@@ -762,7 +781,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
             }
         }
     }
-    if (!live) in.idle(comp, ring_col);
+    if (!live) in.idle(comp, block_ring);
 
     const u32 maxlen = rcx_wave_max(len);
     const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
@@ -770,52 +789,41 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
     const bool leader = live && j == 0;
 
     // One symbol.  CONTRIB receives the symbol in the owning lane and 0 in the quad's other lanes.
-    // A target at or past the total -- possible only on a corrupt stream -- is not decoded here: the
-    // top threshold is taken as above `low` whatever it is (so the node index stays inside the table),
-    // the block is marked in `redo`, and rcx_dec_adaptive_k decodes marked blocks again with the
-    // reference's fall-through (cpprcoder.h:1220-1242).
-    bool past_total = false;
-    const bool last = j == 3;
-    const u32 T2 = T0 + 2, T3 = T0 + 3, T4 = T0 + 4;
+    u32 fewest_above = 16; // over all symbols, of the bounds above low in round 1: 0 = a target past the total
 #define RCX_QUAD_DEC_SYMBOL(K, CONTRIB)                                                                    \
     {                                                                                                      \
         in.pull();                                                                                         \
         const DivQ k_ = (K);                                                                               \
         const u32 t_ = (u32)(((u64)in.range * k_.mul + k_.add) >> 32) >> (k_.st & 31u); /* :904 */          \
         /* round 1: which of the 16 nodes */                                                               \
-        const u32 x0_ = in.low - rcx_mul24(S0, t_);                                                        \
-        u32 x1_, x2_, x3_;                                                                                 \
-        u32 above_ = __builtin_usub_overflow(in.low, rcx_mul24(S1, t_), &x1_) ? 1u : 0u;                   \
-        above_ += __builtin_usub_overflow(in.low, rcx_mul24(S2, t_), &x2_) ? 1u : 0u;                      \
-        above_ += __builtin_usub_overflow(in.low, rcx_mul24(S3, t_), &x3_) ? 1u : 0u;                      \
-        const bool below4_ = in.low < rcx_mul24(S4, t_);                                                   \
-        past_total |= !below4_; /* meaningful in the last lane, whose S4 is the total */                   \
-        above_ += (below4_ || last) ? 1u : 0u;                                                             \
+        u32 x1_, x2_, x3_, x4_;                                                                            \
+        u32 above_ = __builtin_usub_overflow(in.low, rcx_mul24(U1, t_), &x1_) ? 1u : 0u;                   \
+        above_ += __builtin_usub_overflow(in.low, rcx_mul24(U2, t_), &x2_) ? 1u : 0u;                      \
+        above_ += __builtin_usub_overflow(in.low, rcx_mul24(U3, t_), &x3_) ? 1u : 0u;                      \
+        above_ += __builtin_usub_overflow(in.low, rcx_mul24(U4_, t_), &x4_) ? 1u : 0u;                     \
         above_ = rcx_quad_sum(above_);                                                                     \
-        const u32 rem_ = rcx_quad_min(rcx_umin(rcx_umin(x0_, x1_), rcx_umin(x2_, x3_)));                   \
+        const u32 rem_ = rcx_quad_min(rcx_umin(rcx_umin(rcx_umin(x1_, x2_), rcx_umin(x3_, x4_)), in.low)); \
         const u32 node_ = 16u - above_;                                                                    \
         /* round 2: which of the node's 16 symbols */                                                      \
         U4* lg_ = leaves + node_ * 4;                                                                      \
         const U4 l_ = *lg_;                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
-        /* meanwhile cpprcoder.h:1134-1177: +1 on every cumulative sum above the node.  Five compares    */ \
-        /* into five mask registers, then five add-with-carry: no compare result is used right away.     */ \
+        /* meanwhile cpprcoder.h:1134-1177: +1 on every cumulative sum above the node.  Four compares    */ \
+        /* into four mask registers, then four add-with-carry: no compare result is used right away.     */ \
         {                                                                                                  \
-            u64 c0_, c1_, c2_, c3_, c4_;                                                                   \
-            asm volatile("v_cmp_lt_u32_e64 %[c0], %[n], %[t0]\n\t"                                         \
-                         "v_cmp_le_u32_e64 %[c1], %[n], %[t0]\n\t"                                         \
+            u64 c1_, c2_, c3_, c4_;                                                                        \
+            asm volatile("v_cmp_lt_u32_e64 %[c1], %[n], %[t1]\n\t"                                         \
                          "v_cmp_lt_u32_e64 %[c2], %[n], %[t2]\n\t"                                         \
                          "v_cmp_lt_u32_e64 %[c3], %[n], %[t3]\n\t"                                         \
-                         "v_cmp_lt_u32_e64 %[c4], %[n], %[t4]\n\t"                                         \
-                         "v_addc_co_u32_e64 %[s0], %[c0], 0, %[s0], %[c0]\n\t"                             \
-                         "v_addc_co_u32_e64 %[s1], %[c1], 0, %[s1], %[c1]\n\t"                             \
-                         "v_addc_co_u32_e64 %[s2], %[c2], 0, %[s2], %[c2]\n\t"                             \
-                         "v_addc_co_u32_e64 %[s3], %[c3], 0, %[s3], %[c3]\n\t"                             \
-                         "v_addc_co_u32_e64 %[s4], %[c4], 0, %[s4], %[c4]"                                 \
-                         : [s0] "+v"(S0), [s1] "+v"(S1), [s2] "+v"(S2), [s3] "+v"(S3), [s4] "+v"(S4),      \
-                           [c0] "=&s"(c0_), [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_),             \
-                           [c4] "=&s"(c4_)                                                                 \
-                         : [n] "v"(node_), [t0] "v"(T0), [t2] "v"(T2), [t3] "v"(T3), [t4] "v"(T4));        \
+                         "v_cmp_le_u32_e64 %[c4], %[n], %[t3]\n\t"                                         \
+                         "v_min_u32 %[f], %[f], %[a]\n\t"                                                  \
+                         "v_addc_co_u32_e64 %[u1], %[c1], 0, %[u1], %[c1]\n\t"                             \
+                         "v_addc_co_u32_e64 %[u2], %[c2], 0, %[u2], %[c2]\n\t"                             \
+                         "v_addc_co_u32_e64 %[u3], %[c3], 0, %[u3], %[c3]\n\t"                             \
+                         "v_addc_co_u32_e64 %[u4], %[c4], 0, %[u4], %[c4]"                                 \
+                         : [u1] "+v"(U1), [u2] "+v"(U2), [u3] "+v"(U3), [u4] "+v"(U4_), [f] "+v"(fewest_above), \
+                           [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_), [c4] "=&s"(c4_)              \
+                         : [n] "v"(node_), [a] "v"(above_), [t1] "v"(T1), [t2] "v"(T2), [t3] "v"(T3));     \
         }                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
         const u32 t2_ = l_.x + l_.y, t3_ = t2_ + l_.z, t4_ = t3_ + l_.w;                                   \
@@ -826,89 +834,81 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
         above2_ += __builtin_usub_overflow(d2_, rcx_mul24(t2_, t_), &xb_) ? 1u : 0u;                       \
         above2_ += __builtin_usub_overflow(d2_, rcx_mul24(t3_, t_), &xc_) ? 1u : 0u;                       \
         const bool own_ = __builtin_usub_overflow(d2_, rcx_mul24(t4_, t_), &xe_);                          \
-        const u32 lo_ = rcx_umin(rcx_umin(d2_, xa_), rcx_umin(xb_, xc_));                                  \
-        const u32 hi_ = rcx_umax(rcx_umax(xa_, xb_), rcx_umax(xc_, xe_));                                  \
-        in.low = rcx_quad_min(lo_);                       /* :906 */                                       \
-        in.range = rcx_quad_sum(own_ ? lo_ - hi_ : 0u);   /* :907 */                                       \
+        const u32 lo_ = rcx_quad_min(rcx_umin(rcx_umin(d2_, xa_), rcx_umin(xb_, xc_)));                    \
+        const u32 hi_ = rcx_quad_max(rcx_umax(rcx_umax(xa_, xb_), rcx_umax(xc_, xe_)));                    \
+        in.low = lo_;            /* :906 */                                                                \
+        in.range = lo_ - hi_;    /* :907 */                                                                \
         const u32 p_ = 3u - above2_;                                                                       \
         rcx_lds_add(reinterpret_cast<u32*>(lg_) + p_, own_ ? 1u : 0u); /* :916 */                           \
         (CONTRIB) = own_ ? node_ * 16u + T0 + p_ : 0u;                                                     \
     }
 
-    DivEntry ahead = divtab[lane];
+    DivEntry ahead = divtab[lane % RCX_QUAD_STAGE];
+#define RCX_QUAD_RESTAGE(I0)                                                                               \
+    {                                                                                                      \
+        DivQ q_;                                                                                           \
+        q_.mul = ahead.mul;                                                                                \
+        q_.st = (ahead.total << 5) | ahead.shift;                                                          \
+        q_.add = ahead.add;                                                                                \
+        stage[lane % RCX_QUAD_STAGE] = q_; /* two lanes per entry, same value */                           \
+        ahead = divtab[(I0) + RCX_QUAD_STAGE + lane % RCX_QUAD_STAGE];                                     \
+    }
     if (full) {
-        for (u32 i0 = 0; i0 < maxlen; i0 += RCX_STAGE) {
-            {
-                DivQ q;
-                q.mul = ahead.mul;
-                q.st = (ahead.total << 5) | ahead.shift;
-                q.add = ahead.add;
-                stage[lane] = q;
-            }
-            ahead = divtab[i0 + RCX_STAGE + lane];
-            const u32 jend = (maxlen - i0) < RCX_STAGE ? (maxlen - i0) : RCX_STAGE;
-            // 64 decoded bytes are held and stored as four back-to-back 16-byte stores, so that L2 sees whole
-            // 64-byte pieces (16-byte pieces 16 symbols apart were written to HBM one by one: 4x WRITE_SIZE)
-            U4 held[4];
-            for (u32 j0 = 0; j0 < jend; j0 += 16) {
-                u32 word[4] = {0, 0, 0, 0};
-                in.topup();
-                DivQ k_next = stage[j0];
+        // 64 decoded bytes are held and stored as four back-to-back 16-byte stores, so that L2 sees whole
+        // 64-byte pieces (16-byte pieces 16 symbols apart were written to HBM one by one: 4x WRITE_SIZE)
+        U4 held[4];
+        for (u32 i0 = 0; i0 < maxlen; i0 += 16) {
+            if (i0 % RCX_QUAD_STAGE == 0) RCX_QUAD_RESTAGE(i0);
+            u32 word[4] = {0, 0, 0, 0};
+            in.topup();
+            const u32 j0 = i0 % RCX_QUAD_STAGE;
+            DivQ k_next = stage[j0];
 #pragma unroll
-                for (u32 s = 0; s < 16; ++s) {
-                    u32 part;
-                    const DivQ kk = k_next;
-                    if (s + 1 < 16) k_next = stage[j0 + s + 1];
-                    RCX_QUAD_DEC_SYMBOL(kk, part);
-                    word[s >> 2] |= part << (8 * (s & 3));
-                }
-                U4 o;
-                o.x = rcx_quad_or(word[0]);
-                o.y = rcx_quad_or(word[1]);
-                o.z = rcx_quad_or(word[2]);
-                o.w = rcx_quad_or(word[3]);
-                if (j0 == 0) held[0] = o;
-                else if (j0 == 16) held[1] = o;
-                else if (j0 == 32) held[2] = o;
-                else held[3] = o;
+            for (u32 s = 0; s < 16; ++s) {
+                u32 part;
+                const DivQ kk = k_next;
+                if (s + 1 < 16) k_next = stage[j0 + s + 1];
+                RCX_QUAD_DEC_SYMBOL(kk, part);
+                word[s >> 2] |= part << (8 * (s & 3));
             }
-            if (leader) {
-                U4* o4 = reinterpret_cast<U4*>(out + i0);
+            U4 o;
+            o.x = rcx_quad_or(word[0]);
+            o.y = rcx_quad_or(word[1]);
+            o.z = rcx_quad_or(word[2]);
+            o.w = rcx_quad_or(word[3]);
+            const u32 g = (i0 >> 4) & 3u;
+            if (g == 0) held[0] = o;
+            else if (g == 1) held[1] = o;
+            else if (g == 2) held[2] = o;
+            else held[3] = o;
+            if ((g == 3 || i0 + 16 >= maxlen) && leader) {
+                U4* o4 = reinterpret_cast<U4*>(out + (i0 & ~63u));
                 o4[0] = held[0];
-                if (jend > 16) o4[1] = held[1];
-                if (jend > 32) o4[2] = held[2];
-                if (jend > 48) o4[3] = held[3];
+                if (g > 0) o4[1] = held[1];
+                if (g > 1) o4[2] = held[2];
+                if (g > 2) o4[3] = held[3];
             }
         }
     } else {
-        for (u32 i0 = 0; i0 < maxlen; i0 += RCX_STAGE) {
-            {
-                DivQ q;
-                q.mul = ahead.mul;
-                q.st = (ahead.total << 5) | ahead.shift;
-                q.add = ahead.add;
-                stage[lane] = q;
-            }
-            ahead = divtab[i0 + RCX_STAGE + lane];
-            const u32 jend = (maxlen - i0) < RCX_STAGE ? (maxlen - i0) : RCX_STAGE;
-            for (u32 s = 0; s < jend; ++s) {
-                const u32 i = i0 + s;
-                const DivQ k = stage[s];
-                if ((s & 15u) == 0) in.topup();
-                if (i < len) { // the 4 lanes of a quad agree
-                    u32 part;
-                    RCX_QUAD_DEC_SYMBOL(k, part);
-                    part = rcx_quad_or(part);
-                    if (leader) out[i] = (u8)part;
-                }
+        for (u32 i = 0; i < maxlen; ++i) {
+            if (i % RCX_QUAD_STAGE == 0) RCX_QUAD_RESTAGE(i);
+            const DivQ k = stage[i % RCX_QUAD_STAGE];
+            if ((i & 15u) == 0) in.topup();
+            if (i < len) { // the 4 lanes of a quad agree
+                u32 part;
+                RCX_QUAD_DEC_SYMBOL(k, part);
+                part = rcx_quad_or(part);
+                if (leader) out[i] = (u8)part;
             }
         }
     }
 #undef RCX_QUAD_DEC_SYMBOL
+#undef RCX_QUAD_RESTAGE
     // a marked block is judged (truncated or not) by the kernel that decodes it again
-    const bool marked = rcx_quad_or((last && live && past_total) ? 1u : 0u) != 0;
+    const bool marked = live && fewest_above == 0;
     if (leader && !marked && in.taken() > stream_len) rcx_flag(status, RCX_ST_CORRUPT, blk);
-    if (last && blk < nblocks) redo[blk] = marked ? 1u : 0u;
+    if (leader) redo[blk] = marked ? 1u : 0u;
+    else if (j == 0 && blk < nblocks) redo[blk] = 0;
 }
 
 // ===========================================================================

@@ -1,0 +1,107 @@
+// ubench.hip -- instruction-cost microbenchmarks for gfx950 (diagnostic tool, not part of librcx.so).
+//
+// One wave (optionally several per SIMD) runs REPS copies of a short instruction pattern between two
+// s_memtime reads; the program prints shader-clock cycles per copy.  Used to decide between
+// instruction sequences in the coder kernels (what does an s_nop cost a lone wave, is v_mad_u64_u32
+// full rate, what is the LDS latency of a dependent ds_read_b128, what does a taken branch cost).
+//
+//   hipcc --offload-arch=gfx950 -O2 -o build/ubench tools/diag/ubench.hip && build/ubench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define REPS 256
+#define STR2(x) #x
+#define STR(x) STR2(x)
+
+#define BENCH_KERNEL(name, setup, body)                                                          \
+    __global__ void name(unsigned long long* out, unsigned* sink)                                 \
+    {                                                                                             \
+        __shared__ unsigned lds[4096];                                                            \
+        for (int i = threadIdx.x; i < 4096; i += blockDim.x) lds[i] = 0;                          \
+        __syncthreads();                                                                          \
+        unsigned v0 = threadIdx.x, v1 = 3, v2 = 5, v3 = 7;                                        \
+        unsigned long long t0, t1;                                                                \
+        asm volatile(setup "\n\ts_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %[t0]\n\ts_waitcnt lgkmcnt(0)\n\t" \
+                     ".rept " STR(REPS) "\n\t" body "\n\t.endr\n\t"                                \
+                     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %[t1]\n\ts_waitcnt lgkmcnt(0)"  \
+                     : [t0] "=&s"(t0), [t1] "=&s"(t1), [a] "+v"(v0), [b] "+v"(v1), [c] "+v"(v2), [d] "+v"(v3) \
+                     :                                                                            \
+                     : "vcc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "v40", "v41", "v42", \
+                       "v43", "v44", "v45", "v46", "v47", "memory");                             \
+        if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;                                \
+        sink[threadIdx.x] = v0 + v1 + v2 + v3 + lds[threadIdx.x];                                 \
+    }
+
+BENCH_KERNEL(k_add_dep, "", "v_add_u32 %[a], %[a], %[b]")
+BENCH_KERNEL(k_add_indep, "", "v_add_u32 %[a], %[b], %[c]\n\tv_add_u32 %[d], %[b], %[c]")
+BENCH_KERNEL(k_mul24, "", "v_mul_u32_u24 %[a], %[a], %[b]")
+BENCH_KERNEL(k_mad64, "v_mov_b32 v40, 1\n\tv_mov_b32 v41, 0", "v_mad_u64_u32 v[40:41], s[20:21], %[a], %[b], v[40:41]")
+BENCH_KERNEL(k_mulhi, "", "v_mul_hi_u32 %[a], %[a], %[b]")
+BENCH_KERNEL(k_mullo, "", "v_mul_lo_u32 %[a], %[a], %[b]")
+BENCH_KERNEL(k_lshl64, "v_mov_b32 v40, 1\n\tv_mov_b32 v41, 0", "v_lshlrev_b64 v[40:41], %[b], v[40:41]")
+BENCH_KERNEL(k_add_nop0, "", "v_add_u32 %[a], %[a], %[b]\n\ts_nop 0")
+BENCH_KERNEL(k_add_nop1, "", "v_add_u32 %[a], %[a], %[b]\n\ts_nop 1")
+BENCH_KERNEL(k_add_nop3, "", "v_add_u32 %[a], %[a], %[b]\n\ts_nop 3")
+BENCH_KERNEL(k_dpp_dep, "", "s_nop 1\n\tv_add_u32_dpp %[a], %[a], %[a] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+BENCH_KERNEL(k_dpp_fill, "", "v_add_u32 %[c], %[c], %[b]\n\tv_add_u32 %[d], %[d], %[b]\n\tv_add_u32_dpp %[a], %[a], %[a] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+BENCH_KERNEL(k_cmp_addc, "", "v_cmp_lt_u32 vcc, %[a], %[b]\n\ts_nop 1\n\tv_addc_co_u32 %[c], vcc, 0, %[c], vcc")
+BENCH_KERNEL(k_cmp5_addc5, "",
+             "v_cmp_lt_u32_e64 s[20:21], %[a], %[b]\n\tv_cmp_lt_u32_e64 s[22:23], %[a], %[c]\n\tv_cmp_lt_u32_e64 s[24:25], %[a], %[d]\n\t"
+             "v_cmp_lt_u32_e64 s[26:27], %[b], %[c]\n\tv_cmp_lt_u32_e64 s[28:29], %[b], %[d]\n\t"
+             "v_addc_co_u32_e64 v40, s[20:21], 0, v40, s[20:21]\n\tv_addc_co_u32_e64 v41, s[22:23], 0, v41, s[22:23]\n\t"
+             "v_addc_co_u32_e64 v42, s[24:25], 0, v42, s[24:25]\n\tv_addc_co_u32_e64 v43, s[26:27], 0, v43, s[26:27]\n\t"
+             "v_addc_co_u32_e64 v44, s[28:29], 0, v44, s[28:29]")
+BENCH_KERNEL(k_min3, "", "v_min3_u32 %[a], %[a], %[b], %[c]")
+BENCH_KERNEL(k_perm, "", "v_perm_b32 %[a], %[a], %[b], %[c]")
+BENCH_KERNEL(k_alignbit, "", "v_alignbit_b32 %[a], %[a], %[b], %[c]")
+BENCH_KERNEL(k_lds_b32, "v_mov_b32 v40, 0", "ds_read_b32 v40, v40\n\ts_waitcnt lgkmcnt(0)")
+BENCH_KERNEL(k_lds_b64, "v_mov_b32 v40, 0", "ds_read_b64 v[40:41], v40\n\ts_waitcnt lgkmcnt(0)")
+BENCH_KERNEL(k_lds_b128, "v_lshlrev_b32 v40, 4, %[a]\n\tv_mov_b32 v45, v40", "ds_read_b128 v[40:43], v45\n\ts_waitcnt lgkmcnt(0)\n\tv_or_b32 v45, v45, v40")
+BENCH_KERNEL(k_lds_b128_same, "v_mov_b32 v40, 0\n\tv_mov_b32 v45, v40", "ds_read_b128 v[40:43], v45\n\ts_waitcnt lgkmcnt(0)\n\tv_or_b32 v45, v45, v40")
+BENCH_KERNEL(k_lds_read2, "v_lshlrev_b32 v40, 2, %[a]", "ds_read2_b32 v[40:41], v40 offset1:16\n\ts_waitcnt lgkmcnt(0)\n\tv_and_b32 v40, 0xfc, v40")
+BENCH_KERNEL(k_lds_add, "v_lshlrev_b32 v40, 2, %[a]", "ds_add_u32 v40, %[b]")
+BENCH_KERNEL(k_lds_add_read, "v_lshlrev_b32 v40, 4, %[a]\n\tv_mov_b32 v45, v40", "ds_add_u32 v45, %[b]\n\tds_read_b128 v[40:43], v45\n\ts_waitcnt lgkmcnt(0)\n\tv_and_b32 v45, 0x3f0, v45")
+BENCH_KERNEL(k_branch_taken, "", "s_branch 1f\n\tv_add_u32 %[a], %[a], %[b]\n1:\n\tv_add_u32 %[c], %[c], %[b]")
+BENCH_KERNEL(k_branch_not, "s_mov_b64 vcc, 0", "s_cbranch_vccnz 1f\n\tv_add_u32 %[c], %[c], %[b]\n1:")
+BENCH_KERNEL(k_cbranch_taken, "s_mov_b64 vcc, 0", "s_cbranch_vccz 1f\n\tv_add_u32 %[a], %[a], %[b]\n1:\n\tv_add_u32 %[c], %[c], %[b]")
+BENCH_KERNEL(k_cvt_rcp, "", "v_cvt_f32_u32 %[a], %[a]\n\tv_rcp_f32 %[a], %[a]")
+BENCH_KERNEL(k_ffbh, "", "v_ffbh_u32 %[a], %[a]")
+BENCH_KERNEL(k_readlane, "", "v_readfirstlane_b32 s20, %[a]\n\tv_add_u32 %[a], s20, %[a]")
+BENCH_KERNEL(k_salu, "", "s_add_u32 s20, s20, 1")
+BENCH_KERNEL(k_valu_salu, "", "v_add_u32 %[a], %[a], %[b]\n\ts_add_u32 s20, s20, 1")
+
+struct Case {
+    const char* name;
+    void (*fn)(unsigned long long*, unsigned*);
+    int per; // instructions of interest per copy, for the reader
+};
+
+int main(int argc, char** argv)
+{
+    const int waves = argc > 1 ? atoi(argv[1]) : 1; // waves per workgroup (1 = a lone wave on its SIMD)
+    const int wgs = argc > 2 ? atoi(argv[2]) : 1;
+    unsigned long long* out;
+    unsigned* sink;
+    hipMalloc(&out, 8);
+    hipMalloc(&sink, 4096 * 4);
+#define C(k, per) {#k, k, per}
+    std::vector<Case> cases = {C(k_add_dep, 1), C(k_add_indep, 2), C(k_mul24, 1), C(k_mad64, 1), C(k_mulhi, 1), C(k_mullo, 1),
+                               C(k_lshl64, 1), C(k_add_nop0, 2), C(k_add_nop1, 2), C(k_add_nop3, 2), C(k_dpp_dep, 2), C(k_dpp_fill, 3),
+                               C(k_cmp_addc, 3), C(k_cmp5_addc5, 10), C(k_min3, 1), C(k_perm, 1), C(k_alignbit, 1), C(k_lds_b32, 1),
+                               C(k_lds_b64, 1), C(k_lds_b128, 2), C(k_lds_b128_same, 2), C(k_lds_read2, 2), C(k_lds_add, 1), C(k_lds_add_read, 3),
+                               C(k_branch_taken, 2), C(k_branch_not, 2), C(k_cbranch_taken, 2), C(k_cvt_rcp, 2), C(k_ffbh, 1),
+                               C(k_readlane, 2), C(k_salu, 1), C(k_valu_salu, 2)};
+    printf("waves/workgroup %d, workgroups %d, %d copies per measurement\n", waves, wgs, REPS);
+    for (auto& c : cases) {
+        unsigned long long best = ~0ull;
+        for (int r = 0; r < 5; ++r) {
+            hipLaunchKernelGGL(c.fn, dim3(wgs), dim3(64 * waves), 0, 0, out, sink);
+            unsigned long long h = 0;
+            hipMemcpy(&h, out, 8, hipMemcpyDeviceToHost);
+            if (h < best) best = h;
+        }
+        printf("%-18s %8.2f cycles per copy (%d instr)\n", c.name, (double)best / REPS, c.per);
+    }
+    return 0;
+}
