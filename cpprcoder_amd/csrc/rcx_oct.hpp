@@ -639,6 +639,7 @@ struct QuadInput {
     u32 low, range;
     u32 bp8;        // bits of the stream consumed, counted from `origin`
     u32 w0, w1;     // ring dwords (bp8 >> 5) and (bp8 >> 5) + 1, raw (memory order)
+    u32 n4;         // the four stream bytes at bp8, first one on top
     u32* ring;      // this block's ring; ring - 16 is its 64-byte scratch area
     u32 wr;         // dwords written to the ring so far
     u32 nfit;       // how many of pendA, pendB (requested at the last top-up) the ring has room for
@@ -684,6 +685,7 @@ struct QuadInput {
         body8 = 8u * (u32)(body - origin);
         bp8 = body8;
         fetch_pair();
+        n4 = rcx_bswap(rcx_funnel_shr(w1, w0, bp8));
         return declared;
     }
     // a lane without a block: reads 16 bytes at the start of the compressed buffer, over and over
@@ -699,7 +701,7 @@ struct QuadInput {
         pendA.x = pendA.y = pendA.z = pendA.w = 0;
         pendB = pendA;
         body8 = bp8 = 0;
-        w0 = w1 = 0;
+        w0 = w1 = n4 = 0;
     }
     __device__ __forceinline__ void topup()
     {
@@ -717,16 +719,6 @@ struct QuadInput {
     }
     // stream bytes consumed so far, header included (cpprcoder.h:901-903)
     __device__ __forceinline__ u64 taken() const { return 8 + (u64)((bp8 - body8) >> 3); }
-    // cpprcoder.h:926-940
-    __device__ __forceinline__ void pull()
-    {
-        const u32 next4 = rcx_bswap(rcx_funnel_shr(w1, w0, bp8)); // the 4 bytes at bp8, first one on top
-        const u32 k8 = rcx_clz(range) & 0x18u;
-        low = (u32)((((u64)low << 32) | next4) << k8 >> 32);
-        range <<= k8;
-        bp8 += k8;
-        fetch_pair(); // for the next symbol
-    }
 };
 
 // A workgroup is WAVES independent waves: with few blocks, 4 waves per workgroup land one on each SIMD of a
@@ -789,58 +781,118 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
     const bool leader = live && j == 0;
 
     // One symbol.  CONTRIB receives the symbol in the owning lane and 0 in the quad's other lanes.
-    u32 fewest_above = 16; // over all symbols, of the bounds above low in round 1: 0 = a target past the total
+    //
+    // The three arithmetic cores are written out as instruction sequences: a lone wave pays 4 cycles
+    // for every s_nop the compiler has to put between a compare and the use of its mask, or between
+    // a vector write and a DPP read of it (2 wait states each on gfx950), so compares go to four
+    // different mask registers before any is used, and every DPP step has two independent
+    // instructions in front of it.  Only register-to-register vector instructions are in there;
+    // LDS and global accesses stay with the compiler (and its s_waitcnt placement).
+    u32 most_below = 0; // over all symbols, of the bounds at or below low in round 1: 16 = a target past the total
+    const u32 T0p3 = T0 + 3;
+    u32* mine32 = reinterpret_cast<u32*>(mine);
+#define RCX_QP1 "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define RCX_QP2 "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
 #define RCX_QUAD_DEC_SYMBOL(K, CONTRIB)                                                                    \
     {                                                                                                      \
-        in.pull();                                                                                         \
+        /* cpprcoder.h:926-940 (in.n4 = the next four stream bytes, ready since the previous symbol) */    \
+        const u32 k8_ = rcx_clz(in.range) & 0x18u;                                                         \
+        in.low = (u32)((((u64)in.low << 32) | in.n4) << k8_ >> 32);                                        \
+        in.range <<= k8_;                                                                                  \
         const DivQ k_ = (K);                                                                               \
         const u32 t_ = (u32)(((u64)in.range * k_.mul + k_.add) >> 32) >> (k_.st & 31u); /* :904 */          \
-        /* round 1: which of the 16 nodes */                                                               \
-        u32 x1_, x2_, x3_, x4_;                                                                            \
-        u32 above_ = __builtin_usub_overflow(in.low, rcx_mul24(U1, t_), &x1_) ? 1u : 0u;                   \
-        above_ += __builtin_usub_overflow(in.low, rcx_mul24(U2, t_), &x2_) ? 1u : 0u;                      \
-        above_ += __builtin_usub_overflow(in.low, rcx_mul24(U3, t_), &x3_) ? 1u : 0u;                      \
-        above_ += __builtin_usub_overflow(in.low, rcx_mul24(U4_, t_), &x4_) ? 1u : 0u;                     \
-        above_ = rcx_quad_sum(above_);                                                                     \
-        const u32 rem_ = rcx_quad_min(rcx_umin(rcx_umin(rcx_umin(x1_, x2_), rcx_umin(x3_, x4_)), in.low)); \
-        const u32 node_ = 16u - above_;                                                                    \
+        /* round 1: which of the 16 nodes.  node = bounds at or below low, rem = low - the largest */      \
+        const u32 a1_ = rcx_mul24(U1, t_), a2_ = rcx_mul24(U2, t_), a3_ = rcx_mul24(U3, t_);               \
+        const u32 a4_ = rcx_mul24(U4_, t_);                                                                \
+        u32 node_, rem_, ro_, x1_, x2_, x3_, x4_;                                                          \
+        u64 c1_, c2_, c3_, c4_;                                                                            \
+        asm volatile("v_sub_co_u32_e64 %[x1], %[c1], %[low], %[a1]\n\t"                                    \
+                     "v_sub_co_u32_e64 %[x2], %[c2], %[low], %[a2]\n\t"                                    \
+                     "v_sub_co_u32_e64 %[x3], %[c3], %[low], %[a3]\n\t"                                    \
+                     "v_sub_co_u32_e64 %[x4], %[c4], %[low], %[a4]\n\t"                                    \
+                     "v_subb_co_u32_e64 %[nd], %[c1], 4, 0, %[c1]\n\t"                                     \
+                     "v_min3_u32 %[rm], %[x1], %[x2], %[x3]\n\t"                                           \
+                     "v_subb_co_u32_e64 %[nd], %[c2], %[nd], 0, %[c2]\n\t"                                 \
+                     "v_min3_u32 %[rm], %[rm], %[x4], %[low]\n\t"                                          \
+                     "v_subb_co_u32_e64 %[nd], %[c3], %[nd], 0, %[c3]\n\t"                                 \
+                     "v_subb_co_u32_e64 %[nd], %[c4], %[nd], 0, %[c4]\n\t"                                 \
+                     "v_min_u32_dpp %[rm], %[rm], %[rm] " RCX_QP1                                          \
+                     "v_add_u32 %[bp], %[bp], %[k8]\n\t" /* the stream position moves on */                \
+                     "v_add_u32_dpp %[nd], %[nd], %[nd] " RCX_QP1                                          \
+                     "v_min_u32_dpp %[rm], %[rm], %[rm] " RCX_QP2                                          \
+                     "v_bfe_u32 %[ro], %[bp], 5, 5\n\t" /* ring slot of the next pair */                   \
+                     "v_add_u32_dpp %[nd], %[nd], %[nd] " RCX_QP2                                          \
+                     : [nd] "=&v"(node_), [rm] "=&v"(rem_), [ro] "=&v"(ro_), [bp] "+v"(in.bp8),            \
+                       [x1] "=&v"(x1_), [x2] "=&v"(x2_), [x3] "=&v"(x3_), [x4] "=&v"(x4_),                 \
+                       [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_), [c4] "=&s"(c4_)                  \
+                     : [low] "v"(in.low), [a1] "v"(a1_), [a2] "v"(a2_), [a3] "v"(a3_), [a4] "v"(a4_),      \
+                       [k8] "v"(k8_));                                                                     \
         /* round 2: which of the node's 16 symbols */                                                      \
-        U4* lg_ = leaves + node_ * 4;                                                                      \
-        const U4 l_ = *lg_;                                                                                \
+        const U4 l_ = leaves[node_ * 4];                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
-        /* meanwhile cpprcoder.h:1134-1177: +1 on every cumulative sum above the node.  Four compares    */ \
-        /* into four mask registers, then four add-with-carry: no compare result is used right away.     */ \
         {                                                                                                  \
-            u64 c1_, c2_, c3_, c4_;                                                                        \
-            asm volatile("v_cmp_lt_u32_e64 %[c1], %[n], %[t1]\n\t"                                         \
-                         "v_cmp_lt_u32_e64 %[c2], %[n], %[t2]\n\t"                                         \
-                         "v_cmp_lt_u32_e64 %[c3], %[n], %[t3]\n\t"                                         \
-                         "v_cmp_le_u32_e64 %[c4], %[n], %[t3]\n\t"                                         \
-                         "v_min_u32 %[f], %[f], %[a]\n\t"                                                  \
-                         "v_addc_co_u32_e64 %[u1], %[c1], 0, %[u1], %[c1]\n\t"                             \
-                         "v_addc_co_u32_e64 %[u2], %[c2], 0, %[u2], %[c2]\n\t"                             \
-                         "v_addc_co_u32_e64 %[u3], %[c3], 0, %[u3], %[c3]\n\t"                             \
-                         "v_addc_co_u32_e64 %[u4], %[c4], 0, %[u4], %[c4]"                                 \
-                         : [u1] "+v"(U1), [u2] "+v"(U2), [u3] "+v"(U3), [u4] "+v"(U4_), [f] "+v"(fewest_above), \
-                           [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_), [c4] "=&s"(c4_)              \
-                         : [n] "v"(node_), [a] "v"(above_), [t1] "v"(T1), [t2] "v"(T2), [t3] "v"(T3));     \
+            const u32* at_ = in.ring + ro_; /* for the next symbol: never waited for */                    \
+            in.w0 = at_[0];                                                                                \
+            in.w1 = at_[1];                                                                                \
         }                                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-        const u32 t2_ = l_.x + l_.y, t3_ = t2_ + l_.z, t4_ = t3_ + l_.w;                                   \
-        const u32 ex_ = rcx_quad_excl_scan(t4_, m1, m2);                                                   \
-        const u32 d2_ = rem_ - rcx_mul24(ex_, t_);                                                         \
-        u32 xa_, xb_, xc_, xe_;                                                                            \
-        u32 above2_ = __builtin_usub_overflow(d2_, rcx_mul24(l_.x, t_), &xa_) ? 1u : 0u;                   \
-        above2_ += __builtin_usub_overflow(d2_, rcx_mul24(t2_, t_), &xb_) ? 1u : 0u;                       \
-        above2_ += __builtin_usub_overflow(d2_, rcx_mul24(t3_, t_), &xc_) ? 1u : 0u;                       \
-        const bool own_ = __builtin_usub_overflow(d2_, rcx_mul24(t4_, t_), &xe_);                          \
-        const u32 lo_ = rcx_quad_min(rcx_umin(rcx_umin(d2_, xa_), rcx_umin(xb_, xc_)));                    \
-        const u32 hi_ = rcx_quad_max(rcx_umax(rcx_umax(xa_, xb_), rcx_umax(xc_, xe_)));                    \
-        in.low = lo_;            /* :906 */                                                                \
-        in.range = lo_ - hi_;    /* :907 */                                                                \
-        const u32 p_ = 3u - above2_;                                                                       \
-        rcx_lds_add(reinterpret_cast<u32*>(lg_) + p_, own_ ? 1u : 0u); /* :916 */                           \
-        (CONTRIB) = own_ ? node_ * 16u + T0 + p_ : 0u;                                                     \
+        /* meanwhile cpprcoder.h:1134-1177: +1 on every cumulative sum above the node */                   \
+        u32 sb_;                                                                                           \
+        asm volatile("v_cmp_lt_u32_e64 %[c1], %[n], %[t1]\n\t"                                             \
+                     "v_cmp_lt_u32_e64 %[c2], %[n], %[t2]\n\t"                                             \
+                     "v_cmp_lt_u32_e64 %[c3], %[n], %[t3]\n\t"                                             \
+                     "v_cmp_le_u32_e64 %[c4], %[n], %[t3]\n\t"                                             \
+                     "v_max_u32 %[mb], %[mb], %[n]\n\t"                                                    \
+                     "v_addc_co_u32_e64 %[u1], %[c1], 0, %[u1], %[c1]\n\t"                                 \
+                     "v_addc_co_u32_e64 %[u2], %[c2], 0, %[u2], %[c2]\n\t"                                 \
+                     "v_addc_co_u32_e64 %[u3], %[c3], 0, %[u3], %[c3]\n\t"                                 \
+                     "v_addc_co_u32_e64 %[u4], %[c4], 0, %[u4], %[c4]\n\t"                                 \
+                     "v_lshl_add_u32 %[sb], %[n], 4, %[t0p3]" /* symbol, if none of the lane's bounds is above */ \
+                     : [u1] "+v"(U1), [u2] "+v"(U2), [u3] "+v"(U3), [u4] "+v"(U4_), [mb] "+v"(most_below),  \
+                       [sb] "=&v"(sb_), [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_), [c4] "=&s"(c4_) \
+                     : [n] "v"(node_), [t1] "v"(T1), [t2] "v"(T2), [t3] "v"(T3), [t0p3] "v"(T0p3));        \
+        u32 lo_, rg_, sym_, own_, q2_, q3_, q4_, qa_, qb_, qc_, qe_, tot_, pre_, o2_, d2_, ya_, yb_, yc_, ye_, hi_; \
+        asm volatile("v_add_u32 %[q2], %[lx], %[ly]\n\t"                                                   \
+                     "v_add_u32 %[q3], %[q2], %[lz]\n\t"                                                   \
+                     "v_add_u32 %[q4], %[q3], %[lw]\n\t"                                                   \
+                     "v_mul_u32_u24 %[qa], %[lx], %[t]\n\t"                                                \
+                     "v_mul_u32_u24 %[qb], %[q2], %[t]\n\t"                                                \
+                     "v_add_u32_dpp %[tot], %[q4], %[q4] " RCX_QP1                                         \
+                     "v_and_b32_dpp %[pre], %[q4], %[m1] " RCX_QP1                                         \
+                     "v_mul_u32_u24 %[qc], %[q3], %[t]\n\t"                                                \
+                     "v_mul_u32_u24 %[qe], %[q4], %[t]\n\t"                                                \
+                     "v_and_b32_dpp %[o2], %[tot], %[m2] " RCX_QP2                                         \
+                     "v_add_u32 %[pre], %[pre], %[o2]\n\t"   /* counts of the node's symbols in lower lanes */ \
+                     "v_mul_u32_u24 %[o2], %[pre], %[t]\n\t"                                               \
+                     "v_sub_u32 %[d2], %[rem], %[o2]\n\t"                                                  \
+                     "v_sub_co_u32_e64 %[ya], %[c1], %[d2], %[qa]\n\t"                                     \
+                     "v_sub_co_u32_e64 %[yb], %[c2], %[d2], %[qb]\n\t"                                     \
+                     "v_sub_co_u32_e64 %[yc], %[c3], %[d2], %[qc]\n\t"                                     \
+                     "v_sub_co_u32_e64 %[ye], %[c4], %[d2], %[qe]\n\t"                                     \
+                     "v_min3_u32 %[lo], %[d2], %[ya], %[yb]\n\t"                                           \
+                     "v_max3_u32 %[hi], %[ya], %[yb], %[yc]\n\t"                                           \
+                     "v_min_u32 %[lo], %[lo], %[yc]\n\t"                                                   \
+                     "v_max_u32 %[hi], %[hi], %[ye]\n\t"                                                   \
+                     "v_subb_co_u32_e64 %[sym], %[c1], %[sb], 0, %[c1]\n\t"                                \
+                     "v_min_u32_dpp %[lo], %[lo], %[lo] " RCX_QP1                                          \
+                     "v_subb_co_u32_e64 %[sym], %[c2], %[sym], 0, %[c2]\n\t"                               \
+                     "v_max_u32_dpp %[hi], %[hi], %[hi] " RCX_QP1                                          \
+                     "v_subb_co_u32_e64 %[sym], %[c3], %[sym], 0, %[c3]\n\t"                               \
+                     "v_min_u32_dpp %[lo], %[lo], %[lo] " RCX_QP2                                          \
+                     "v_cndmask_b32_e64 %[own], 0, 1, %[c4]\n\t"                                           \
+                     "v_max_u32_dpp %[hi], %[hi], %[hi] " RCX_QP2                                          \
+                     "v_sub_u32 %[rg], %[lo], %[hi]"                                                       \
+                     : [lo] "=&v"(lo_), [rg] "=&v"(rg_), [sym] "=&v"(sym_), [own] "=&v"(own_), [q2] "=&v"(q2_), \
+                       [q3] "=&v"(q3_), [q4] "=&v"(q4_), [qa] "=&v"(qa_), [qb] "=&v"(qb_), [qc] "=&v"(qc_),  \
+                       [qe] "=&v"(qe_), [tot] "=&v"(tot_), [pre] "=&v"(pre_), [o2] "=&v"(o2_), [d2] "=&v"(d2_), \
+                       [ya] "=&v"(ya_), [yb] "=&v"(yb_), [yc] "=&v"(yc_), [ye] "=&v"(ye_), [hi] "=&v"(hi_),  \
+                       [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_), [c4] "=&s"(c4_)                  \
+                     : [lx] "v"(l_.x), [ly] "v"(l_.y), [lz] "v"(l_.z), [lw] "v"(l_.w), [t] "v"(t_),        \
+                       [rem] "v"(rem_), [m1] "v"(m1), [m2] "v"(m2), [sb] "v"(sb_));                        \
+        in.low = lo_;   /* :906 */                                                                         \
+        in.range = rg_; /* :907 */                                                                         \
+        rcx_lds_add(mine32 + sym_, own_); /* :916; the count of symbol c is the block's dword c */          \
+        (CONTRIB) = rcx_mul24(sym_, own_);                                                                 \
+        in.n4 = rcx_bswap(rcx_funnel_shr(in.w1, in.w0, in.bp8)); /* the 4 bytes at bp8, first one on top */ \
     }
 
     DivEntry ahead = divtab[lane % RCX_QUAD_STAGE];
@@ -904,8 +956,10 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
     }
 #undef RCX_QUAD_DEC_SYMBOL
 #undef RCX_QUAD_RESTAGE
+#undef RCX_QP1
+#undef RCX_QP2
     // a marked block is judged (truncated or not) by the kernel that decodes it again
-    const bool marked = live && fewest_above == 0;
+    const bool marked = live && most_below == 16;
     if (leader && !marked && in.taken() > stream_len) rcx_flag(status, RCX_ST_CORRUPT, blk);
     if (leader) redo[blk] = marked ? 1u : 0u;
     else if (j == 0 && blk < nblocks) redo[blk] = 0;
