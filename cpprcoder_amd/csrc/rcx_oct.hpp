@@ -576,8 +576,9 @@ __global__ __launch_bounds__(RCX_MC_THREADS) void rcx_enc_mc_k(const u8* __restr
 // ===========================================================================
 #define RCX_QUAD_BLOCKS 16
 #define RCX_QUAD_STAGE 32 /* divisor entries staged per refill */
-// one block in LDS: 256 counts | 64 scratch bytes ("node 16", and where skipped ring writes go) |
-// ring of 32 dwords | ring slot 32 (repeats slot 0) + 12 spare bytes.  1232 / 4 = 52 (mod 64): the 16
+// one block in LDS: 256 counts | 64 scratch bytes ("node 16": three 16-byte groups of decoded output waiting
+// for the fourth, then 16 bytes where skipped ring writes go) | ring of 32 dwords | ring slot 32 (repeats
+// slot 0) + 12 spare bytes.  1232 / 4 = 52 (mod 64): the 16
 // blocks of a wave start 4 banks apart.
 #define RCX_QUAD_BLOCK_BYTES 1232
 #define RCX_QUAD_SCRATCH_OFF 1024
@@ -640,7 +641,7 @@ struct QuadInput {
     u32 bp8;        // bits of the stream consumed, counted from `origin`
     u32 w0, w1;     // ring dwords (bp8 >> 5) and (bp8 >> 5) + 1, raw (memory order)
     u32 n4;         // the four stream bytes at bp8, first one on top
-    u32* ring;      // this block's ring; ring - 16 is its 64-byte scratch area
+    u32* ring;      // this block's ring; the 16 bytes before it take the writes that are skipped
     u32 wr;         // dwords written to the ring so far
     u32 nfit;       // how many of pendA, pendB (requested at the last top-up) the ring has room for
     U4 pendA, pendB;
@@ -657,7 +658,7 @@ struct QuadInput {
     __device__ __forceinline__ void ring_put(const U4& piece, bool really)
     {
         const u32 slot = wr % RCX_RING_DW; // a multiple of 4: the piece never wraps
-        *reinterpret_cast<U4*>(really ? ring + slot : ring - 16) = piece;
+        *reinterpret_cast<U4*>(really ? ring + slot : ring - 4) = piece;
         ring[really && slot == 0 ? RCX_RING_DW : RCX_RING_DW + 1] = piece.x;
         wr += really ? 4u : 0u;
     }
@@ -780,7 +781,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
     u8* out = dst + at;
     const bool leader = live && j == 0;
 
-    // One symbol.  CONTRIB receives the symbol in the owning lane and 0 in the quad's other lanes.
+    // One symbol; the owning lane ORs it into WORD at bit SHIFT (the quad's other lanes OR in 0).
     //
     // The three arithmetic cores are written out as instruction sequences: a lone wave pays 4 cycles
     // for every s_nop the compiler has to put between a compare and the use of its mask, or between
@@ -793,7 +794,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
     u32* mine32 = reinterpret_cast<u32*>(mine);
 #define RCX_QP1 "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
 #define RCX_QP2 "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-#define RCX_QUAD_DEC_SYMBOL(K, CONTRIB)                                                                    \
+#define RCX_QUAD_DEC_SYMBOL(K, WORD, SHIFT)                                                                   \
     {                                                                                                      \
         /* cpprcoder.h:926-940 (in.n4 = the next four stream bytes, ready since the previous symbol) */    \
         const u32 k8_ = rcx_clz(in.range) & 0x18u;                                                         \
@@ -880,18 +881,19 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
                      "v_min_u32_dpp %[lo], %[lo], %[lo] " RCX_QP2                                          \
                      "v_cndmask_b32_e64 %[own], 0, 1, %[c4]\n\t"                                           \
                      "v_max_u32_dpp %[hi], %[hi], %[hi] " RCX_QP2                                          \
-                     "v_sub_u32 %[rg], %[lo], %[hi]"                                                       \
+                     "v_cndmask_b32_e64 %[ye], 0, %[sym], %[c4]\n\t"                                       \
+                     "v_sub_u32 %[rg], %[lo], %[hi]\n\t"                                                   \
+                     "v_lshl_or_b32 %[word], %[ye], %[sh], %[word]"                                        \
                      : [lo] "=&v"(lo_), [rg] "=&v"(rg_), [sym] "=&v"(sym_), [own] "=&v"(own_), [q2] "=&v"(q2_), \
                        [q3] "=&v"(q3_), [q4] "=&v"(q4_), [qa] "=&v"(qa_), [qb] "=&v"(qb_), [qc] "=&v"(qc_),  \
                        [qe] "=&v"(qe_), [tot] "=&v"(tot_), [pre] "=&v"(pre_), [o2] "=&v"(o2_), [d2] "=&v"(d2_), \
                        [ya] "=&v"(ya_), [yb] "=&v"(yb_), [yc] "=&v"(yc_), [ye] "=&v"(ye_), [hi] "=&v"(hi_),  \
-                       [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_), [c4] "=&s"(c4_)                  \
+                       [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_), [c4] "=&s"(c4_), [word] "+v"(WORD) \
                      : [lx] "v"(l_.x), [ly] "v"(l_.y), [lz] "v"(l_.z), [lw] "v"(l_.w), [t] "v"(t_),        \
-                       [rem] "v"(rem_), [m1] "v"(m1), [m2] "v"(m2), [sb] "v"(sb_));                        \
+                       [rem] "v"(rem_), [m1] "v"(m1), [m2] "v"(m2), [sb] "v"(sb_), [sh] "n"(SHIFT));       \
         in.low = lo_;   /* :906 */                                                                         \
         in.range = rg_; /* :907 */                                                                         \
         rcx_lds_add(mine32 + sym_, own_); /* :916; the count of symbol c is the block's dword c */          \
-        (CONTRIB) = rcx_mul24(sym_, own_);                                                                 \
         in.n4 = rcx_bswap(rcx_funnel_shr(in.w1, in.w0, in.bp8)); /* the 4 bytes at bp8, first one on top */ \
     }
 
@@ -906,40 +908,54 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
         ahead = divtab[(I0) + RCX_QUAD_STAGE + lane % RCX_QUAD_STAGE];                                     \
     }
     if (full) {
-        // 64 decoded bytes are held and stored as four back-to-back 16-byte stores, so that L2 sees whole
-        // 64-byte pieces (16-byte pieces 16 symbols apart were written to HBM one by one: 4x WRITE_SIZE)
-        U4 held[4];
+        // 64 decoded bytes leave as four back-to-back 16-byte stores, so that L2 sees whole 64-byte pieces
+        // (16-byte pieces 16 symbols apart were written to HBM one by one: 4x WRITE_SIZE).  Groups 0..2 wait
+        // in the block's scratch area, group 3 in registers, and the stores are issued right AFTER the next
+        // top-up: its s_waitcnt vmcnt for the input pieces would otherwise wait for these stores as well.
+        U4* parked = reinterpret_cast<U4*>(mine + RCX_QUAD_SCRATCH_OFF);
+        U4 o_last;
+        o_last.x = o_last.y = o_last.z = o_last.w = 0;
         for (u32 i0 = 0; i0 < maxlen; i0 += 16) {
             if (i0 % RCX_QUAD_STAGE == 0) RCX_QUAD_RESTAGE(i0);
-            u32 word[4] = {0, 0, 0, 0};
             in.topup();
+            const u32 g = (i0 >> 4) & 3u;
+            if (g == 0 && i0 != 0 && leader) {
+                U4* o4 = reinterpret_cast<U4*>(out + (i0 - 64));
+                const U4 p0 = parked[0], p1 = parked[1], p2 = parked[2];
+                o4[0] = p0;
+                o4[1] = p1;
+                o4[2] = p2;
+                o4[3] = o_last;
+            }
+            u32 w0_ = 0, w1_ = 0, w2_ = 0, w3_ = 0;
             const u32 j0 = i0 % RCX_QUAD_STAGE;
             DivQ k_next = stage[j0];
-#pragma unroll
-            for (u32 s = 0; s < 16; ++s) {
-                u32 part;
-                const DivQ kk = k_next;
-                if (s + 1 < 16) k_next = stage[j0 + s + 1];
-                RCX_QUAD_DEC_SYMBOL(kk, part);
-                word[s >> 2] |= part << (8 * (s & 3));
-            }
+#define RCX_QUAD_STEP(S, W)                                      \
+    {                                                            \
+        const DivQ kk = k_next;                                  \
+        if ((S) + 1 < 16) k_next = stage[j0 + (S) + 1];          \
+        RCX_QUAD_DEC_SYMBOL(kk, W, 8 * ((S) & 3));               \
+    }
+            RCX_QUAD_STEP(0, w0_) RCX_QUAD_STEP(1, w0_) RCX_QUAD_STEP(2, w0_) RCX_QUAD_STEP(3, w0_)
+            RCX_QUAD_STEP(4, w1_) RCX_QUAD_STEP(5, w1_) RCX_QUAD_STEP(6, w1_) RCX_QUAD_STEP(7, w1_)
+            RCX_QUAD_STEP(8, w2_) RCX_QUAD_STEP(9, w2_) RCX_QUAD_STEP(10, w2_) RCX_QUAD_STEP(11, w2_)
+            RCX_QUAD_STEP(12, w3_) RCX_QUAD_STEP(13, w3_) RCX_QUAD_STEP(14, w3_) RCX_QUAD_STEP(15, w3_)
+#undef RCX_QUAD_STEP
             U4 o;
-            o.x = rcx_quad_or(word[0]);
-            o.y = rcx_quad_or(word[1]);
-            o.z = rcx_quad_or(word[2]);
-            o.w = rcx_quad_or(word[3]);
-            const u32 g = (i0 >> 4) & 3u;
-            if (g == 0) held[0] = o;
-            else if (g == 1) held[1] = o;
-            else if (g == 2) held[2] = o;
-            else held[3] = o;
-            if ((g == 3 || i0 + 16 >= maxlen) && leader) {
-                U4* o4 = reinterpret_cast<U4*>(out + (i0 & ~63u));
-                o4[0] = held[0];
-                if (g > 0) o4[1] = held[1];
-                if (g > 1) o4[2] = held[2];
-                if (g > 2) o4[3] = held[3];
-            }
+            o.x = rcx_quad_or(w0_);
+            o.y = rcx_quad_or(w1_);
+            o.z = rcx_quad_or(w2_);
+            o.w = rcx_quad_or(w3_);
+            if (g == 3) o_last = o;
+            else parked[g] = o; // the quad's 4 lanes store the same 16 bytes
+        }
+        if (leader && maxlen != 0) { // what is still parked: the last 16..64 bytes of the block
+            const u32 groups = ((maxlen - 1) >> 4 & 3u) + 1;
+            U4* o4 = reinterpret_cast<U4*>(out + ((maxlen - 1) & ~63u));
+            o4[0] = parked[0];
+            if (groups > 1) o4[1] = parked[1];
+            if (groups > 2) o4[2] = parked[2];
+            if (groups > 3) o4[3] = o_last;
         }
     } else {
         for (u32 i = 0; i < maxlen; ++i) {
@@ -947,8 +963,8 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
             const DivQ k = stage[i % RCX_QUAD_STAGE];
             if ((i & 15u) == 0) in.topup();
             if (i < len) { // the 4 lanes of a quad agree
-                u32 part;
-                RCX_QUAD_DEC_SYMBOL(k, part);
+                u32 part = 0;
+                RCX_QUAD_DEC_SYMBOL(k, part, 0);
                 part = rcx_quad_or(part);
                 if (leader) out[i] = (u8)part;
             }
