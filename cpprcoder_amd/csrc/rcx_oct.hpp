@@ -575,7 +575,7 @@ __global__ __launch_bounds__(RCX_MC_THREADS) void rcx_enc_mc_k(const u8* __restr
 // never waited for) and the next four bytes are one v_alignbit + one byte swap away.
 // ===========================================================================
 #define RCX_QUAD_BLOCKS 16
-#define RCX_QUAD_STAGE 32 /* divisor entries staged per refill */
+#define RCX_QUAD_STAGE 16 /* divisor entries staged per refill: one top-up interval */
 // one block in LDS: 256 counts | 64 scratch bytes ("node 16": three 16-byte groups of decoded output waiting
 // for the fourth, then 16 bytes where skipped ring writes go) | ring of 32 dwords | ring slot 32 (repeats
 // slot 0) + 12 spare bytes.  1232 / 4 = 52 (mod 64): the 16
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(RCX_MC_THREADS) void rcx_enc_mc_k(const u8* __restr
 #define RCX_QUAD_BLOCK_BYTES 1232
 #define RCX_QUAD_SCRATCH_OFF 1024
 #define RCX_QUAD_RING_OFF 1088
-#define RCX_QUAD_LDS_BYTES (RCX_QUAD_STAGE * 16 + RCX_QUAD_BLOCKS * RCX_QUAD_BLOCK_BYTES) /* 19.75 KiB: two 4-wave workgroups per CU */
+#define RCX_QUAD_LDS_BYTES (RCX_QUAD_STAGE * 16 + RCX_QUAD_BLOCKS * RCX_QUAD_BLOCK_BYTES) /* 19.5 KiB: two 4-wave workgroups per CU */
 
 // divisor entry as the quad decoder stages it: the 64-bit addend is read as a register pair
 struct alignas(16) DivQ {
@@ -897,16 +897,19 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
         in.n4 = rcx_bswap(rcx_funnel_shr(in.w1, in.w0, in.bp8)); /* the 4 bytes at bp8, first one on top */ \
     }
 
+    // The divisors of the next 16 symbols are converted and written to LDS at every top-up, and the 16 after
+    // those requested from the table right after the top-up's own loads: every s_waitcnt vmcnt in the loop
+    // then waits for loads issued 16 symbols earlier, never for one that has just been issued.
     DivEntry ahead = divtab[lane % RCX_QUAD_STAGE];
-#define RCX_QUAD_RESTAGE(I0)                                                                               \
+#define RCX_QUAD_STAGE_PUT()                                                                               \
     {                                                                                                      \
         DivQ q_;                                                                                           \
         q_.mul = ahead.mul;                                                                                \
         q_.st = (ahead.total << 5) | ahead.shift;                                                          \
         q_.add = ahead.add;                                                                                \
-        stage[lane % RCX_QUAD_STAGE] = q_; /* two lanes per entry, same value */                           \
-        ahead = divtab[(I0) + RCX_QUAD_STAGE + lane % RCX_QUAD_STAGE];                                     \
+        stage[lane % RCX_QUAD_STAGE] = q_; /* four lanes per entry, same value */                          \
     }
+#define RCX_QUAD_STAGE_GET(I0) ahead = divtab[(I0) + RCX_QUAD_STAGE + lane % RCX_QUAD_STAGE];
     if (full) {
         // 64 decoded bytes leave as four back-to-back 16-byte stores, so that L2 sees whole 64-byte pieces
         // (16-byte pieces 16 symbols apart were written to HBM one by one: 4x WRITE_SIZE).  Groups 0..2 wait
@@ -916,8 +919,9 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
         U4 o_last;
         o_last.x = o_last.y = o_last.z = o_last.w = 0;
         for (u32 i0 = 0; i0 < maxlen; i0 += 16) {
-            if (i0 % RCX_QUAD_STAGE == 0) RCX_QUAD_RESTAGE(i0);
+            RCX_QUAD_STAGE_PUT();
             in.topup();
+            RCX_QUAD_STAGE_GET(i0);
             const u32 g = (i0 >> 4) & 3u;
             if (g == 0 && i0 != 0 && leader) {
                 U4* o4 = reinterpret_cast<U4*>(out + (i0 - 64));
@@ -928,12 +932,11 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
                 o4[3] = o_last;
             }
             u32 w0_ = 0, w1_ = 0, w2_ = 0, w3_ = 0;
-            const u32 j0 = i0 % RCX_QUAD_STAGE;
-            DivQ k_next = stage[j0];
+            DivQ k_next = stage[0];
 #define RCX_QUAD_STEP(S, W)                                      \
     {                                                            \
         const DivQ kk = k_next;                                  \
-        if ((S) + 1 < 16) k_next = stage[j0 + (S) + 1];          \
+        if ((S) + 1 < 16) k_next = stage[(S) + 1];          \
         RCX_QUAD_DEC_SYMBOL(kk, W, 8 * ((S) & 3));               \
     }
             RCX_QUAD_STEP(0, w0_) RCX_QUAD_STEP(1, w0_) RCX_QUAD_STEP(2, w0_) RCX_QUAD_STEP(3, w0_)
@@ -959,9 +962,12 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
         }
     } else {
         for (u32 i = 0; i < maxlen; ++i) {
-            if (i % RCX_QUAD_STAGE == 0) RCX_QUAD_RESTAGE(i);
+            if ((i & 15u) == 0) {
+                RCX_QUAD_STAGE_PUT();
+                in.topup();
+                RCX_QUAD_STAGE_GET(i);
+            }
             const DivQ k = stage[i % RCX_QUAD_STAGE];
-            if ((i & 15u) == 0) in.topup();
             if (i < len) { // the 4 lanes of a quad agree
                 u32 part = 0;
                 RCX_QUAD_DEC_SYMBOL(k, part, 0);
@@ -971,7 +977,8 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
         }
     }
 #undef RCX_QUAD_DEC_SYMBOL
-#undef RCX_QUAD_RESTAGE
+#undef RCX_QUAD_STAGE_PUT
+#undef RCX_QUAD_STAGE_GET
 #undef RCX_QP1
 #undef RCX_QP2
     // a marked block is judged (truncated or not) by the kernel that decodes it again

@@ -8,6 +8,7 @@
 //   hipcc --offload-arch=gfx950 -O2 -o build/ubench tools/diag/ubench.hip && build/ubench
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #define REPS 256
@@ -71,6 +72,63 @@ BENCH_KERNEL(k_readlane, "", "v_readfirstlane_b32 s20, %[a]\n\tv_add_u32 %[a], s
 BENCH_KERNEL(k_salu, "", "s_add_u32 s20, s20, 1")
 BENCH_KERNEL(k_valu_salu, "", "v_add_u32 %[a], %[a], %[b]\n\ts_add_u32 s20, s20, 1")
 
+
+// ---------------------------------------------------------------------------------------------
+// The quad decoder's LDS pattern: per "symbol" one broadcast ds_read2_b64, PRE dependent VALU ops, a
+// ds_read_b128 whose address differs per quad (16 distinct 64-byte windows), a ds_read2_b32, GAP
+// independent VALU ops, s_waitcnt lgkmcnt(1) + use, POST VALU ops, a ds_add.  Run with 4 waves per
+// workgroup (one per SIMD, as in the kernel); cycles per copy minus 4 x (instructions) = exposed wait.
+// ---------------------------------------------------------------------------------------------
+#define REP4(x) x x x x
+#define REP8(x) REP4(x) REP4(x)
+#define REP16(x) REP8(x) REP8(x)
+#define VADD "v_add_u32 %[a], %[a], %[b]\n\t"
+#define VIND "v_add_u32 %[c], %[c], %[b]\n\t"
+#define SYM_KERNEL(name, gap, leafread, atomic)                                                    \
+    __global__ void name(unsigned long long* out, unsigned* sink)                                 \
+    {                                                                                             \
+        __shared__ unsigned lds[20480];                                                           \
+        for (int i = threadIdx.x; i < 20480; i += blockDim.x) lds[i] = 0;                         \
+        __syncthreads();                                                                          \
+        const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 2, j = lane & 3; \
+        unsigned v0 = threadIdx.x, v1 = 0, v2 = 5, v3 = 7;                                        \
+        unsigned base = wave * 20480;                                                             \
+        unsigned leaf = base + 512 + q * 1232 + ((q * 7 + wave * 3) & 15) * 64 + j * 16;          \
+        unsigned ring = base + 512 + q * 1232 + 1088 + ((q * 5) & 31) * 4;                        \
+        unsigned cnt = base + 512 + q * 1232 + (((q * 11) & 15) * 16 + j * 4 + (q & 3)) * 4;      \
+        unsigned long long t0, t1;                                                                \
+        asm volatile("v_mov_b32 v50, %[kb]\n\tv_mov_b32 v51, %[lf]\n\tv_mov_b32 v52, %[rg]\n\tv_mov_b32 v53, %[ct]\n\t" \
+                     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %[t0]\n\ts_waitcnt lgkmcnt(0)\n\t" \
+                     ".rept " STR(REPS) "\n\t"                                                     \
+                     "ds_read2_b64 v[40:43], v50 offset1:1\n\t" REP16(VADD) REP4(VADD)            \
+                     leafread "\n\t"                                                               \
+                     "ds_read2_b32 v[48:49], v52 offset1:1\n\t" gap                               \
+                     "s_waitcnt lgkmcnt(1)\n\tv_or_b32 %[a], %[a], v44\n\t" REP16(VADD) REP8(VADD) REP4(VADD) \
+                     atomic REP4(VADD)                                                             \
+                     "s_waitcnt lgkmcnt(1)\n\tv_or_b32 %[a], %[a], v48\n\tv_or_b32 %[a], %[a], v40\n\t" \
+                     ".endr\n\t"                                                                   \
+                     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %[t1]\n\ts_waitcnt lgkmcnt(0)"  \
+                     : [t0] "=&s"(t0), [t1] "=&s"(t1), [a] "+v"(v0), [b] "+v"(v1), [c] "+v"(v2), [d] "+v"(v3) \
+                     : [kb] "v"(base), [lf] "v"(leaf), [rg] "v"(ring), [ct] "v"(cnt)              \
+                     : "vcc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", \
+                       "v52", "v53", "memory");                                                   \
+        if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;                                \
+        sink[threadIdx.x & 4095] = v0 + v1 + v2 + v3 + lds[threadIdx.x];                          \
+    }
+#define LEAF128 "ds_read_b128 v[44:47], v51"
+#define LEAF64 "ds_read_b64 v[44:45], v51"
+#define ATOM "ds_add_u32 v53, %[b]\n\t"
+SYM_KERNEL(k_sym_gap0, "", LEAF128, ATOM)
+SYM_KERNEL(k_sym_gap4, REP4(VIND), LEAF128, ATOM)
+SYM_KERNEL(k_sym_gap8, REP8(VIND), LEAF128, ATOM)
+SYM_KERNEL(k_sym_gap12, REP8(VIND) REP4(VIND), LEAF128, ATOM)
+SYM_KERNEL(k_sym_gap16, REP16(VIND), LEAF128, ATOM)
+SYM_KERNEL(k_sym_gap24, REP16(VIND) REP8(VIND), LEAF128, ATOM)
+SYM_KERNEL(k_sym_gap32, REP16(VIND) REP16(VIND), LEAF128, ATOM)
+SYM_KERNEL(k_sym_gap12_noatom, REP8(VIND) REP4(VIND), LEAF128, "")
+SYM_KERNEL(k_sym_gap12_b64, REP8(VIND) REP4(VIND), LEAF64, ATOM)
+SYM_KERNEL(k_sym_gap0_b64, "", LEAF64, ATOM)
+
 struct Case {
     const char* name;
     void (*fn)(unsigned long long*, unsigned*);
@@ -85,15 +143,19 @@ int main(int argc, char** argv)
     unsigned* sink;
     hipMalloc(&out, 8);
     hipMalloc(&sink, 4096 * 4);
+    const char* only = argc > 3 ? argv[3] : nullptr;
 #define C(k, per) {#k, k, per}
     std::vector<Case> cases = {C(k_add_dep, 1), C(k_add_indep, 2), C(k_mul24, 1), C(k_mad64, 1), C(k_mulhi, 1), C(k_mullo, 1),
                                C(k_lshl64, 1), C(k_add_nop0, 2), C(k_add_nop1, 2), C(k_add_nop3, 2), C(k_dpp_dep, 2), C(k_dpp_fill, 3),
                                C(k_cmp_addc, 3), C(k_cmp5_addc5, 10), C(k_min3, 1), C(k_perm, 1), C(k_alignbit, 1), C(k_lds_b32, 1),
                                C(k_lds_b64, 1), C(k_lds_b128, 2), C(k_lds_b128_same, 2), C(k_lds_read2, 2), C(k_lds_add, 1), C(k_lds_add_read, 3),
                                C(k_branch_taken, 2), C(k_branch_not, 2), C(k_cbranch_taken, 2), C(k_cvt_rcp, 2), C(k_ffbh, 1),
-                               C(k_readlane, 2), C(k_salu, 1), C(k_valu_salu, 2)};
+                               C(k_readlane, 2), C(k_salu, 1), C(k_valu_salu, 2),
+                               C(k_sym_gap0, 65), C(k_sym_gap4, 69), C(k_sym_gap8, 73), C(k_sym_gap12, 77), C(k_sym_gap16, 81), C(k_sym_gap24, 89),
+                               C(k_sym_gap32, 97), C(k_sym_gap12_noatom, 76), C(k_sym_gap12_b64, 77), C(k_sym_gap0_b64, 65)};
     printf("waves/workgroup %d, workgroups %d, %d copies per measurement\n", waves, wgs, REPS);
     for (auto& c : cases) {
+        if (only && !strstr(c.name, only)) continue;
         unsigned long long best = ~0ull;
         for (int r = 0; r < 5; ++r) {
             hipLaunchKernelGGL(c.fn, dim3(wgs), dim3(64 * waves), 0, 0, out, sink);
