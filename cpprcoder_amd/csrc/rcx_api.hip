@@ -295,7 +295,7 @@ int rcx_encode_blocks_device(rcx_ctx* c, int coder, const void* d_src, uint64_t 
         } else if (c->enc_variant == 3) {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_enc_mc5_k, dim3(grid), dim3(RCX_MC5_THREADS), 0, s, static_cast<const u8*>(d_src), n, block,
-                               nblocks, c->slots, slot, c->sizes, c->divtab, c->status);
+                               nblocks, c->slots, slot, c->sizes, c->divtab, c->status, c->redo);
         } else if (c->enc_variant == 2) {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_enc_mc_k, dim3(grid), dim3(RCX_MC_THREADS), 0, s, static_cast<const u8*>(d_src), n, block, nblocks,
@@ -307,8 +307,18 @@ int rcx_encode_blocks_device(rcx_ctx* c, int coder, const void* d_src, uint64_t 
         } else {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_enc_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block,
-                               nblocks, c->slots, slot, c->sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr));
+                               nblocks, c->slots, slot, c->sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr),
+                               static_cast<const u32*>(nullptr));
         }
+    }
+    if (coder == RCX_CODER_ADAPTIVE && c->enc_variant == 3) {
+        // Blocks in which a carry ran through more output bytes than the five-wave kernel keeps in LDS were
+        // marked, not finished: the one-wave kernel encodes them again.  Nothing is marked on ordinary data
+        // and every wave of this launch returns at once.
+        const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
+        hipLaunchKernelGGL(rcx_enc_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block,
+                           nblocks, c->slots, slot, c->sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr),
+                           static_cast<const u32*>(c->redo));
     }
     {
         Timed t(c, s, RCX_T_SCAN);
@@ -488,7 +498,7 @@ int rcx_stream_encode(rcx_ctx* c, int coder, const uint8_t* src, uint32_t n,
         return RCX_OK;
     }
     hipLaunchKernelGGL(rcx_enc_adaptive_k<false>, dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)n, block, (u64)1, c->slots, slot,
-                       c->sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr));
+                       c->sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr), static_cast<const u32*>(nullptr));
     if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
     r = rcx_ctx_sync_status(c, nullptr, nullptr);
     if (r != RCX_OK) return r;
@@ -502,7 +512,7 @@ int rcx_stream_encode(rcx_ctx* c, int coder, const uint8_t* src, uint32_t n,
     }
     // The sink fills.  Second pass: replay the reference's delayed writer to find the symbol.
     hipLaunchKernelGGL(rcx_enc_adaptive_k<true>, dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)n, block, (u64)1, c->slots, slot,
-                       c->sizes, c->divtab, c->status, (u32)(cap16 - 4), c->status + 2);
+                       c->sizes, c->divtab, c->status, (u32)(cap16 - 4), c->status + 2, static_cast<const u32*>(nullptr));
     if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
     HIP_TRY(hipMemcpy(c->status_host, c->status, 4 * sizeof(u32), hipMemcpyDeviceToHost));
     const u32 fail_at = c->status_host[2];

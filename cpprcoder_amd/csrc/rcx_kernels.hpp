@@ -57,12 +57,18 @@ template <bool STREAM>
 __global__ __launch_bounds__(64) void rcx_enc_adaptive_k(const u8* __restrict__ src, u64 n, u32 block, u64 nblocks,
                                                          u8* __restrict__ slots, u64 slot, u32* __restrict__ sizes,
                                                          const DivEntry* __restrict__ divtab, u32* status,
-                                                         u32 sink_bytes, u32* track)
+                                                         u32 sink_bytes, u32* track, const u32* __restrict__ only)
 {
     __shared__ U4 lds[RCX_LDS_U4];
     const u32 lane = threadIdx.x;
     const u64 blk = (u64)blockIdx.x * RCX_LANES + lane;
-    const bool live = blk < nblocks;
+    bool live = blk < nblocks;
+    // second pass behind rcx_enc_mc5_k: only the blocks it marked (a carry through more output bytes than
+    // it keeps in LDS: none on ordinary data)
+    if (only) {
+        live = live && only[blk] != 0;
+        if (!__any(live)) return;
+    }
     const u64 at = live ? blk * (u64)block : 0;
     const u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
 

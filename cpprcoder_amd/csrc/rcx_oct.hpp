@@ -810,6 +810,11 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
 #if !defined(RCX_EXP_GAP_PAD) /* experiments (tools/diag): extra idempotent instructions behind the dependent LDS read */
 #define RCX_EXP_GAP_PAD
 #endif
+#if defined(RCX_STAMP_DEC) /* diagnostic build only (tools/diag/stamp_quad.py): where does one symbol's time go? */
+#define RCX_QUAD_STAMP(i) if (stamp_now_) stamp_t_[stamp_at_ + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define RCX_QUAD_STAMP(i)
+#endif
 #if !defined(RCX_EXP_LDS_ADD)
 #define RCX_EXP_LDS_ADD(p, v) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)
 #endif
@@ -851,6 +856,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
                      : [low] "v"(in.low), [a1] "v"(a1_), [a2] "v"(a2_), [a3] "v"(a3_), [a4] "v"(a4_),      \
                        [k8] "v"(k8_), [lvb] "v"(leaves_lds));                                              \
         /* round 2: which of the node's 16 symbols */                                                      \
+        RCX_QUAD_STAMP(0);                                                                                 \
         const RcxV4 l_ = *reinterpret_cast<const RcxLdsV4*>(la_);                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
         {                                                                                                  \
@@ -920,6 +926,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
                        [rem] "v"(rem_), [m1] "v"(m1), [m2] "v"(m2), [sb] "v"(sb_), [sh] "n"(SHIFT),        \
                        [w0] "v"(in.w0), [w1] "v"(in.w1), [bp] "v"(in.bp8), [swap] "s"(0x00010203u),        \
                        [la] "v"(la_));                                                                     \
+        RCX_QUAD_STAMP(1);                                                                                 \
         in.low = lo_;   /* :906 */                                                                         \
         in.range = rg_; /* :907 */                                                                         \
         RCX_EXP_LDS_ADD(reinterpret_cast<RcxLdsU32*>(ye_), own_); /* :916 */                                \
@@ -945,6 +952,9 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
         // top-up: its s_waitcnt vmcnt for the input pieces would otherwise wait for these stores as well.
         U4 o_last;
         o_last.x = o_last.y = o_last.z = o_last.w = 0;
+#if defined(RCX_STAMP_DEC)
+        unsigned long long stamp_sum_[4] = {0, 0, 0, 0};
+#endif
         for (u32 i0 = 0; i0 < maxlen; i0 += 16) {
             RCX_QUAD_STAGE_PUT();
             in.topup();
@@ -960,17 +970,35 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
             }
             u32 w0_ = 0, w1_ = 0, w2_ = 0, w3_ = 0;
             DivQ k_next = stage[0];
+#if defined(RCX_STAMP_DEC)
+            unsigned long long stamp_t_[4] = {0, 0, 0, 0};
 #define RCX_QUAD_STEP(S, W)                                      \
     {                                                            \
         const DivQ kk = k_next;                                  \
-        if ((S) + 1 < 16) k_next = stage[(S) + 1];          \
+        if ((S) + 1 < 16) k_next = stage[(S) + 1];               \
+        const bool stamp_now_ = (S) == 8 || (S) == 9;            \
+        const int stamp_at_ = (S) == 8 ? 0 : 2;                  \
         RCX_QUAD_DEC_SYMBOL(kk, W, 8 * ((S) & 3));               \
     }
+#else
+#define RCX_QUAD_STEP(S, W)                                      \
+    {                                                            \
+        const DivQ kk = k_next;                                  \
+        if ((S) + 1 < 16) k_next = stage[(S) + 1];               \
+        RCX_QUAD_DEC_SYMBOL(kk, W, 8 * ((S) & 3));               \
+    }
+#endif
             RCX_QUAD_STEP(0, w0_) RCX_QUAD_STEP(1, w0_) RCX_QUAD_STEP(2, w0_) RCX_QUAD_STEP(3, w0_)
             RCX_QUAD_STEP(4, w1_) RCX_QUAD_STEP(5, w1_) RCX_QUAD_STEP(6, w1_) RCX_QUAD_STEP(7, w1_)
             RCX_QUAD_STEP(8, w2_) RCX_QUAD_STEP(9, w2_) RCX_QUAD_STEP(10, w2_) RCX_QUAD_STEP(11, w2_)
             RCX_QUAD_STEP(12, w3_) RCX_QUAD_STEP(13, w3_) RCX_QUAD_STEP(14, w3_) RCX_QUAD_STEP(15, w3_)
 #undef RCX_QUAD_STEP
+#if defined(RCX_STAMP_DEC)
+            stamp_sum_[0] += stamp_t_[1] - stamp_t_[0]; // symbol 8: leaf read issued -> round 2 done
+            stamp_sum_[1] += stamp_t_[2] - stamp_t_[1]; // -> leaf read of symbol 9 issued
+            stamp_sum_[2] += stamp_t_[3] - stamp_t_[2]; // symbol 9: leaf read issued -> round 2 done
+            stamp_sum_[3] += 1;
+#endif
             U4 o;
             o.x = rcx_quad_or(w0_);
             o.y = rcx_quad_or(w1_);
@@ -979,6 +1007,10 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
             if (g == 3) o_last = o;
             else parked[g] = o; // the quad's 4 lanes store the same 16 bytes
         }
+#if defined(RCX_STAMP_DEC)
+        if (blockIdx.x == 7 && threadIdx.x == 0)
+            for (int i_ = 0; i_ < 4; ++i_) rcx_dec_stamp_out[i_] = stamp_sum_[i_];
+#endif
         if (leader && maxlen != 0) { // what is still parked: the last 16..64 bytes of the block
             const u32 groups = ((maxlen - 1) >> 4 & 3u) + 1;
             U4* o4 = reinterpret_cast<U4*>(out + ((maxlen - 1) & ~63u));
@@ -997,6 +1029,11 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
             const DivQ k = stage[i % RCX_QUAD_STAGE];
             if (i < len) { // the 4 lanes of a quad agree
                 u32 part = 0;
+#if defined(RCX_STAMP_DEC)
+                const bool stamp_now_ = false;
+                const int stamp_at_ = 0;
+                unsigned long long stamp_t_[4];
+#endif
                 RCX_QUAD_DEC_SYMBOL(k, part, 0);
                 part = rcx_quad_or(part);
                 if (leader) out[i] = (u8)part;
@@ -1024,17 +1061,91 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
 // LDS ring of one record per symbol.  Three pipeline stages, one chunk apart:
 //   waves M1..M3 (model, chunk k) -> wave A (arithmetic, chunk k-1) -> wave W (writer, chunk k-2)
 // Five waves on four SIMDs: the two lightest (A and the level-1 model wave) are meant to share one.
+//
+// The writer does not store to global memory: scattered 4-byte stores under an EXEC mask were its most
+// expensive step.  Its words go to a per-block ring in LDS (one ds_write_b32 per symbol, to a dummy word
+// when nothing is due), and the lightest wave (model level 1) drains the rings once per chunk with 16-byte
+// stores.  The ring keeps the newest RCX_OUT_MARGIN bytes back, so that a carry that runs off the writer's
+// registers (cpprcoder.h:767-781) is resolved in LDS; a run of 0xFF bytes longer than that margin cannot be,
+// and such a block is marked in `redo` and encoded again by rcx_enc_adaptive_k.
 // ===========================================================================
 #define RCX_MC5_THREADS 320
 #define RCX_MC5_RING2_DW (2 * RCX_MC_CHUNK * RCX_LANES)
-#define RCX_MC5_LDS_U4 (RCX_MC_LDS_U4 + RCX_MC5_RING2_DW / 4 + RCX_LANES / 4)
+#define RCX_OUT_RING_WORDS 64 /* per block: 256 bytes of output waiting in LDS */
+#define RCX_OUT_MARGIN 32     /* bytes kept back from the drain */
+#define RCX_MC5_OUT_DW (RCX_OUT_RING_WORDS * RCX_LANES + 3 * RCX_LANES)
+#define RCX_MC5_LDS_U4 (RCX_MC_LDS_U4 + RCX_MC5_RING2_DW / 4 + RCX_LANES / 4 + RCX_MC5_OUT_DW / 4)
+
+struct __attribute__((packed, aligned(4))) RcxU4Unaligned {
+    u32 x, y, z, w;
+};
+
+// `extra` carries ran off the bytes the writer holds in registers: add them into the bytes already in the
+// ring, newest first (cpprcoder.h:767-781).  Returns 1 if the carry wants to go below `safe_from`, where the
+// bytes may have left for global memory already.  Rare (about 9e-5 per symbol on random data): out of line.
+__device__ __attribute__((noinline, cold)) u32 rcx_stage_carry(u32* ring_lane, u32 pos, u32 safe_from, u32 extra)
+{
+    while (extra != 0 && pos > safe_from) {
+        --pos;
+        u32* w = ring_lane + ((pos >> 2) % RCX_OUT_RING_WORDS) * RCX_LANES;
+        const u32 sh = 8u * (pos & 3u); // the ring holds memory-order dwords
+        const u32 old = *w;
+        const u32 v = ((old >> sh) & 0xFFu) + extra;
+        *w = (old & ~(0xFFu << sh)) | ((v & 0xFFu) << sh);
+        extra = v >> 8;
+    }
+    return extra != 0 && pos != 0 ? 1u : 0u; // (a carry out of the very first byte cannot happen: it starts as 0)
+}
+
+// The byte writer of EncLane (emit + flush), with the 4-byte words going to the block's LDS ring.
+struct StagedWriter {
+    u64 acc;        // as EncLane::acc
+    u32 nacc8;
+    u32 pos;        // payload bytes handed to the ring so far
+    u32 safe_from;  // bytes below this may have been drained (pos at the start of the chunk - RCX_OUT_MARGIN)
+    u32 redo;
+    u32* ring_lane; // word w of this block: ring_lane[(w % RCX_OUT_RING_WORDS) * RCX_LANES]
+    u32* dummy;     // takes the store of a symbol that completes no word
+
+    __device__ __forceinline__ void begin(u32* ring, u32* dummies, u32 lane)
+    {
+        acc = 0;
+        nacc8 = 8; // the reference's initial buffer_ = 0 is already "held" (see EncLane)
+        pos = 0;
+        safe_from = 0;
+        redo = 0;
+        ring_lane = ring + lane;
+        dummy = dummies + lane;
+    }
+    __device__ __forceinline__ void emit(u32 rec)
+    {
+        const u32 k8 = (rec << 2) & 0x18u;
+        acc += rec & 1u;                                     // cpprcoder.h:767-781, resolved lazily
+        acc = (acc << k8) | (((u64)rec << k8) >> 32);
+        nacc8 += k8;
+        // with 5..7 bytes held: the 4 oldest leave (EncLane::flush, branch-free)
+        const bool due = nacc8 >= 40;
+        const u32 keep8 = (nacc8 - 32) & 31u;
+        const u32 acc_lo = (u32)acc, acc_hi = (u32)(acc >> 32);
+        const u32 word = rcx_funnel_shr(acc_hi, acc_lo, keep8);
+        const u32 extra = due ? acc_hi >> keep8 : 0u;
+        if (rcx_any(extra != 0)) redo |= rcx_stage_carry(ring_lane, pos, safe_from, extra);
+        u32* at = due ? ring_lane + ((pos >> 2) % RCX_OUT_RING_WORDS) * RCX_LANES : dummy;
+        *at = rcx_bswap(word);
+        const u32 kept = acc_lo & ((1u << keep8) - 1u);
+        acc = due ? (u64)kept : acc;
+        nacc8 -= due ? 32u : 0u;
+        pos += due ? 4u : 0u;
+    }
+};
 
 template <bool FULL>
 __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u32 nchunks, const u8* in,
                                                  const DivEntry* __restrict__ divtab, const Tree& tree, DivEntry* stage,
-                                                 U4* ring, u32* ring2, EncLane& enc, DivEntry& ahead)
+                                                 U4* ring, u32* ring2, EncLane& enc, DivEntry& ahead, StagedWriter& wr,
+                                                 u32* out_pos, u32& drained, u8* payload, u32 cap, bool live)
 {
-    // wave roles: 0 arithmetic, 1 writer, 2 model levels 3+2, 3 model leaf level, 4 model level 1
+    // wave roles: 0 arithmetic, 1 writer, 2 model levels 3+2, 3 model leaf level, 4 model level 1 + drain
 #if defined(RCX_STAMP)
     unsigned long long stamp_wait_ = 0;
     const unsigned long long stamp_begin_ = __builtin_amdgcn_s_memtime();
@@ -1074,14 +1185,36 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
             if (k >= 2) {
                 const u32* rs2 = ring2 + ((k - 2) & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
                 u32 r_next = rs2[0];
+                wr.safe_from = wr.pos > RCX_OUT_MARGIN ? wr.pos - RCX_OUT_MARGIN : 0u;
 #pragma unroll
                 for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
                     const u32 rec = r_next;
                     if (s + 1 < RCX_MC_CHUNK) r_next = rs2[(s + 1) * RCX_LANES];
-                    enc.emit(rec);
+                    wr.emit(rec);
+                }
+                out_pos[lane] = wr.pos; // for the drain of the next iteration
+            }
+        } else {
+          if (wave == 4) {
+            // ---- drain: whole 16-byte pieces below (the writer's position one barrier ago - margin) ----
+            const u32 p = out_pos[lane];
+            const u32 limit = p > RCX_OUT_MARGIN ? (p - RCX_OUT_MARGIN) & ~15u : 0u;
+            while (__any(live && drained + 16 <= limit && drained + 16 <= cap)) {
+                const bool go = live && drained + 16 <= limit && drained + 16 <= cap;
+                if (go) {
+                    const u32* w = wr.ring_lane;
+                    const u32 w0 = drained >> 2;
+                    RcxU4Unaligned piece;
+                    piece.x = w[((w0 + 0) % RCX_OUT_RING_WORDS) * RCX_LANES];
+                    piece.y = w[((w0 + 1) % RCX_OUT_RING_WORDS) * RCX_LANES];
+                    piece.z = w[((w0 + 2) % RCX_OUT_RING_WORDS) * RCX_LANES];
+                    piece.w = w[((w0 + 3) % RCX_OUT_RING_WORDS) * RCX_LANES];
+                    *reinterpret_cast<RcxU4Unaligned*>(payload + drained) = piece;
+                    drained += 16;
                 }
             }
-        } else if (k < nchunks) {
+          }
+          if (k < nchunks) {
             // ---- model: chunk k ----
             const u32 i0 = k * RCX_MC_CHUNK;
             U4* ws = ring + (k & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
@@ -1164,6 +1297,7 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
                     }
                 }
             }
+          }
         }
 #if defined(RCX_STAMP)
         const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
@@ -1183,7 +1317,8 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
 
 __global__ __launch_bounds__(RCX_MC5_THREADS) void rcx_enc_mc5_k(const u8* __restrict__ src, u64 n, u32 block, u64 nblocks,
                                                                 u8* __restrict__ slots, u64 slot, u32* __restrict__ sizes,
-                                                                const DivEntry* __restrict__ divtab, u32* status)
+                                                                const DivEntry* __restrict__ divtab, u32* status,
+                                                                u32* __restrict__ redo)
 {
     __shared__ U4 lds[RCX_MC5_LDS_U4];
     const u32 lane = threadIdx.x & 63u;
@@ -1198,6 +1333,10 @@ __global__ __launch_bounds__(RCX_MC5_THREADS) void rcx_enc_mc5_k(const u8* __res
     U4* ring = lds + RCX_LDS_U4;
     u32* ring2 = reinterpret_cast<u32*>(lds + RCX_MC_LDS_U4);
     u32* final_low = ring2 + RCX_MC5_RING2_DW; // 64 dwords: the arithmetic wave's last low, for the writer's finish()
+    u32* out_ring = final_low + RCX_LANES;     // the writer's words on their way to global memory
+    u32* out_dummy = out_ring + RCX_OUT_RING_WORDS * RCX_LANES;
+    u32* out_pos = out_dummy + RCX_LANES;      // writer -> drain: bytes in the ring so far
+    u32* out_drained = out_pos + RCX_LANES;    // drain -> writer's finish: bytes stored so far
 
     const u32 maxlen = rcx_wave_max(len);
     const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
@@ -1206,7 +1345,10 @@ __global__ __launch_bounds__(RCX_MC5_THREADS) void rcx_enc_mc5_k(const u8* __res
 
     EncLane enc;
     u8* wave_slots = slots + (u64)blockIdx.x * RCX_LANES * slot;
-    enc.idle(wave_slots); // waves 0 and 1 each use their half of the state
+    enc.idle(wave_slots); // wave 0 uses low/range; wave 1 takes over for finish()
+    StagedWriter wr;
+    wr.begin(out_ring, out_dummy, lane);
+    u32 drained = 0;
     DivEntry ahead;
     ahead.mul = ahead.add = ahead.shift = ahead.total = 0;
     U4 v;
@@ -1214,6 +1356,7 @@ __global__ __launch_bounds__(RCX_MC5_THREADS) void rcx_enc_mc5_k(const u8* __res
         ahead = divtab[lane];
     } else if (wave == 1) {
         if (live) enc.begin(wave_slots, lane * (u32)slot, (u32)slot, len);
+        out_pos[lane] = 0;
     } else if (wave == 2) { // cpprcoder.h:1094-1132: every count 1
         v.x = v.y = v.z = v.w = 64;
         tree.base[0] = v;
@@ -1228,15 +1371,31 @@ __global__ __launch_bounds__(RCX_MC5_THREADS) void rcx_enc_mc5_k(const u8* __res
     }
     rcx_lds_barrier();
 
-    if (full) rcx_mc5_pipeline<true>(wave, lane, len, nchunks, in, divtab, tree, stage, ring, ring2, enc, ahead);
-    else rcx_mc5_pipeline<false>(wave, lane, len, nchunks, in, divtab, tree, stage, ring, ring2, enc, ahead);
+    u8* payload = wave_slots + (u64)lane * slot + 4;
+    const u32 cap = ((u32)slot - 4) & ~3u; // as EncLane::begin
+    if (full) rcx_mc5_pipeline<true>(wave, lane, len, nchunks, in, divtab, tree, stage, ring, ring2, enc, ahead, wr, out_pos, drained, payload, cap, live);
+    else rcx_mc5_pipeline<false>(wave, lane, len, nchunks, in, divtab, tree, stage, ring, ring2, enc, ahead, wr, out_pos, drained, payload, cap, live);
 
     if (wave == 0) final_low[lane] = enc.low;
+    if (wave == 4) {
+        out_drained[lane] = drained;
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the drained pieces are in memory before wave 1 may read them
+    }
     rcx_lds_barrier();
     if (wave == 1 && live) {
+        // what is still in the ring, then cpprcoder.h:744-762 as in the one-wave coder
+        u32 at = out_drained[lane];
+        const u32 end = wr.pos < cap ? wr.pos : cap;
+        for (; at < end; at += 4) *reinterpret_cast<u32*>(payload + at) = wr.ring_lane[((at >> 2) % RCX_OUT_RING_WORDS) * RCX_LANES];
         enc.low = final_low[lane];
+        enc.acc = wr.acc;
+        enc.nacc8 = wr.nacc8;
+        enc.pos = wr.pos;
         const u32 bytes = enc.finish();
         sizes[blk] = enc.overflow ? (u32)slot : bytes;
         if (enc.overflow) rcx_flag(status, RCX_ST_CAPACITY, blk);
+        redo[blk] = (wr.redo != 0 && !enc.overflow) ? 1u : 0u;
+    } else if (wave == 1 && blk < nblocks) {
+        redo[blk] = 0;
     }
 }

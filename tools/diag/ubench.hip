@@ -129,6 +129,134 @@ SYM_KERNEL(k_sym_gap12_noatom, REP8(VIND) REP4(VIND), LEAF128, "")
 SYM_KERNEL(k_sym_gap12_b64, REP8(VIND) REP4(VIND), LEAF64, ATOM)
 SYM_KERNEL(k_sym_gap0_b64, "", LEAF64, ATOM)
 
+// The quad decoder's three instruction sequences with fixed registers (timing only: the values are arbitrary).
+#define QP1 " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define QP2 " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define BLOCK_A                                                                   \
+    "v_sub_co_u32_e64 v40, s[20:21], %[a], %[b]\n\t"                              \
+    "v_sub_co_u32_e64 v41, s[22:23], %[a], %[c]\n\t"                              \
+    "v_sub_co_u32_e64 v42, s[24:25], %[a], %[d]\n\t"                              \
+    "v_sub_co_u32_e64 v43, s[26:27], %[a], %[b]\n\t"                              \
+    "v_subb_co_u32_e64 v44, s[20:21], 4, 0, s[20:21]\n\t"                         \
+    "v_min3_u32 v45, v40, v41, v42\n\t"                                           \
+    "v_subb_co_u32_e64 v44, s[22:23], v44, 0, s[22:23]\n\t"                       \
+    "v_min3_u32 v45, v45, v43, %[a]\n\t"                                          \
+    "v_subb_co_u32_e64 v44, s[24:25], v44, 0, s[24:25]\n\t"                       \
+    "v_subb_co_u32_e64 v44, s[26:27], v44, 0, s[26:27]\n\t"                       \
+    "v_min_u32_dpp v45, v45, v45" QP1                                             \
+    "v_add_u32 v46, v46, %[b]\n\t"                                                \
+    "v_add_u32_dpp v44, v44, v44" QP1                                             \
+    "v_min_u32_dpp v45, v45, v45" QP2                                             \
+    "v_bfe_u32 v47, v46, 5, 5\n\t"                                                \
+    "v_add_u32_dpp v44, v44, v44" QP2                                             \
+    "v_lshl_add_u32 %[a], v44, 8, v45\n\t"
+#define BLOCK_U                                                                   \
+    "v_cmp_lt_u32_e64 s[20:21], %[a], %[b]\n\t"                                   \
+    "v_cmp_lt_u32_e64 s[22:23], %[a], %[c]\n\t"                                   \
+    "v_cmp_lt_u32_e64 s[24:25], %[a], %[d]\n\t"                                   \
+    "v_cmp_le_u32_e64 s[26:27], %[a], %[d]\n\t"                                   \
+    "v_addc_co_u32_e64 v40, s[20:21], 0, v40, s[20:21]\n\t"                       \
+    "v_addc_co_u32_e64 v41, s[22:23], 0, v41, s[22:23]\n\t"                       \
+    "v_addc_co_u32_e64 v42, s[24:25], 0, v42, s[24:25]\n\t"                       \
+    "v_addc_co_u32_e64 v43, s[26:27], 0, v43, s[26:27]\n\t"                       \
+    "v_lshl_add_u32 %[a], %[a], 4, v40\n\t"
+#define BLOCK_C                                                                   \
+    "v_add_u32 v40, %[a], %[b]\n\t"                                               \
+    "v_add_u32 v41, v40, %[c]\n\t"                                                \
+    "v_add_u32 v42, v41, %[d]\n\t"                                                \
+    "v_mul_u32_u24 v43, %[a], %[b]\n\t"                                           \
+    "v_mul_u32_u24 v44, v40, %[b]\n\t"                                            \
+    "v_add_u32_dpp v45, v42, v42" QP1                                             \
+    "v_and_b32_dpp v46, v42, %[c]" QP1                                            \
+    "v_mul_u32_u24 v47, v41, %[b]\n\t"                                            \
+    "v_mul_u32_u24 v48, v42, %[b]\n\t"                                            \
+    "v_and_b32_dpp v49, v45, %[d]" QP2                                            \
+    "v_add_u32 v46, v46, v49\n\t"                                                 \
+    "v_mul_u32_u24 v49, v46, %[b]\n\t"                                            \
+    "v_sub_u32 v50, %[a], v49\n\t"                                                \
+    "v_sub_co_u32_e64 v51, s[20:21], v50, v43\n\t"                                \
+    "v_sub_co_u32_e64 v52, s[22:23], v50, v44\n\t"                                \
+    "v_sub_co_u32_e64 v53, s[24:25], v50, v47\n\t"                                \
+    "v_sub_co_u32_e64 v54, s[26:27], v50, v48\n\t"                                \
+    "v_min3_u32 v55, v50, v51, v52\n\t"                                           \
+    "v_max3_u32 v56, v51, v52, v53\n\t"                                           \
+    "v_min_u32 v55, v55, v53\n\t"                                                 \
+    "v_max_u32 v56, v56, v54\n\t"                                                 \
+    "v_subb_co_u32_e64 v57, s[20:21], %[a], 0, s[20:21]\n\t"                      \
+    "v_min_u32_dpp v55, v55, v55" QP1                                             \
+    "v_subb_co_u32_e64 v57, s[22:23], v57, 0, s[22:23]\n\t"                       \
+    "v_max_u32_dpp v56, v56, v56" QP1                                             \
+    "v_subb_co_u32_e64 v57, s[24:25], v57, 0, s[24:25]\n\t"                       \
+    "v_min_u32_dpp v55, v55, v55" QP2                                             \
+    "v_cndmask_b32_e64 v58, 0, 1, s[26:27]\n\t"                                   \
+    "v_max_u32_dpp v56, v56, v56" QP2                                             \
+    "v_cndmask_b32_e64 v54, 0, v57, s[26:27]\n\t"                                 \
+    "v_sub_u32 %[a], v55, v56\n\t"                                                \
+    "v_lshl_or_b32 %[c], v54, 8, %[c]\n\t"                                        \
+    "v_alignbit_b32 v59, %[b], %[d], v50\n\t"                                     \
+    "v_perm_b32 v59, v59, v59, s28\n\t"                                           \
+    "v_and_b32 v54, 3, v57\n\t"                                                   \
+    "v_lshl_add_u32 v54, v54, 2, v55\n\t"
+#define BK(name, body, clob)                                                                      \
+    __global__ void name(unsigned long long* out, unsigned* sink)                                 \
+    {                                                                                             \
+        unsigned v0 = threadIdx.x, v1 = 3, v2 = 5, v3 = 7;                                        \
+        unsigned long long t0, t1;                                                                \
+        asm volatile("s_mov_b32 s28, 0x00010203\n\ts_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %[t0]\n\ts_waitcnt lgkmcnt(0)\n\t" \
+                     ".rept " STR(REPS) "\n\t" body ".endr\n\t"                                    \
+                     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %[t1]\n\ts_waitcnt lgkmcnt(0)"  \
+                     : [t0] "=&s"(t0), [t1] "=&s"(t1), [a] "+v"(v0), [b] "+v"(v1), [c] "+v"(v2), [d] "+v"(v3) \
+                     :                                                                            \
+                     : "vcc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "v40", "v41", "v42", "v43", \
+                       "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", \
+                       "v58", "v59", "memory");                                                   \
+        if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;                                \
+        sink[threadIdx.x & 4095] = v0 + v1 + v2 + v3;                                             \
+    }
+BK(k_blk_a, BLOCK_A, 0)
+BK(k_blk_u, BLOCK_U, 0)
+BK(k_blk_c, BLOCK_C, 0)
+BK(k_blk_auc, BLOCK_A BLOCK_U BLOCK_C, 0)
+
+// the same in a loop that fits the instruction cache: 16 copies x 16 iterations
+#define BKL(name, body)                                                                           \
+    __global__ void name(unsigned long long* out, unsigned* sink)                                 \
+    {                                                                                             \
+        unsigned v0 = threadIdx.x, v1 = 3, v2 = 5, v3 = 7;                                        \
+        unsigned long long t0, t1;                                                                \
+        asm volatile("s_mov_b32 s28, 0x00010203\n\ts_mov_b32 s29, 16\n\ts_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %[t0]\n\ts_waitcnt lgkmcnt(0)\n\t" \
+                     "2:\n\t.rept 16\n\t" body ".endr\n\t"                                         \
+                     "s_sub_u32 s29, s29, 1\n\ts_cmp_lg_u32 s29, 0\n\ts_cbranch_scc1 2b\n\t"       \
+                     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %[t1]\n\ts_waitcnt lgkmcnt(0)"  \
+                     : [t0] "=&s"(t0), [t1] "=&s"(t1), [a] "+v"(v0), [b] "+v"(v1), [c] "+v"(v2), [d] "+v"(v3) \
+                     :                                                                            \
+                     : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "v40", "v41", "v42", "v43", \
+                       "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", \
+                       "v58", "v59", "memory");                                                   \
+        if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;                                \
+        sink[threadIdx.x & 4095] = v0 + v1 + v2 + v3;                                             \
+    }
+BKL(k_loop_auc, BLOCK_A BLOCK_U BLOCK_C)
+BKL(k_loop_add62, REP16(VADD) REP16(VADD) REP16(VADD) REP8(VADD) REP4(VADD) "v_add_u32 %[a], %[a], %[b]\n\tv_add_u32 %[a], %[a], %[b]\n\t")
+BKL(k_loop_min3_62, REP16("v_min3_u32 %[a], %[a], %[b], %[c]\n\t") REP16("v_min3_u32 %[a], %[a], %[b], %[c]\n\t") REP16("v_min3_u32 %[a], %[a], %[b], %[c]\n\t") REP8("v_min3_u32 %[a], %[a], %[b], %[c]\n\t") REP4("v_min3_u32 %[a], %[a], %[b], %[c]\n\t") "v_min3_u32 %[a], %[a], %[b], %[c]\n\tv_min3_u32 %[a], %[a], %[b], %[c]\n\t")
+
+// instruction-size patterns (8 = v_min3_u32, VOP3, 8 bytes; 4 = v_add_u32 e32, 4 bytes; D = v_add_u32_dpp, 8 bytes)
+#define I8 "v_min3_u32 %[a], %[a], %[b], %[c]\n\t"
+#define I4 "v_add_u32 %[a], %[a], %[b]\n\t"
+#define ID "v_add_u32_dpp %[c], %[d], %[d] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+BKL(k_pat_84, REP16(I8 I4) REP8(I8 I4) REP4(I8 I4) I8 I4 I8 I4 I8 I4)
+BKL(k_pat_884, REP16(I8 I8 I4) REP4(I8 I8 I4) I8 I8)
+BKL(k_pat_844, REP16(I8 I4 I4) REP4(I8 I4 I4) I8 I4)
+BKL(k_pat_8884, REP8(I8 I8 I8 I4) REP4(I8 I8 I8 I4) I8 I8 I8 I4 I8 I8 I8 I4 I8 I8 I8 I4 I8 I8)
+BKL(k_pat_D62, REP16(ID) REP16(ID) REP16(ID) REP8(ID) REP4(ID) ID ID)
+
+// VGPR bank conflicts?  sources in one bank (v44, v48, v52) or in three (v45, v50, v55); with a 4-byte filler so that fetch is not the limit
+BKL(k_bank_same3, REP16("v_min3_u32 v40, v44, v48, v52\n\t" I4) REP8("v_min3_u32 v40, v44, v48, v52\n\t" I4) REP4("v_min3_u32 v40, v44, v48, v52\n\t" I4) "v_min3_u32 v40, v44, v48, v52\n\t" I4 "v_min3_u32 v40, v44, v48, v52\n\t" I4 "v_min3_u32 v40, v44, v48, v52\n\t" I4)
+BKL(k_bank_diff3, REP16("v_min3_u32 v40, v45, v50, v55\n\t" I4) REP8("v_min3_u32 v40, v45, v50, v55\n\t" I4) REP4("v_min3_u32 v40, v45, v50, v55\n\t" I4) "v_min3_u32 v40, v45, v50, v55\n\t" I4 "v_min3_u32 v40, v45, v50, v55\n\t" I4 "v_min3_u32 v40, v45, v50, v55\n\t" I4)
+BKL(k_bank_same2, REP16("v_add_u32 v40, v44, v48\n\t") REP16("v_add_u32 v40, v44, v48\n\t") REP16("v_add_u32 v40, v44, v48\n\t") REP8("v_add_u32 v40, v44, v48\n\t") REP4("v_add_u32 v40, v44, v48\n\t") "v_add_u32 v40, v44, v48\n\tv_add_u32 v40, v44, v48\n\t")
+BKL(k_mad64_same, REP16("v_mad_u64_u32 v[40:41], s[20:21], v44, v48, v[52:53]\n\t" I4) REP8("v_mad_u64_u32 v[40:41], s[20:21], v44, v48, v[52:53]\n\t" I4) REP4("v_mad_u64_u32 v[40:41], s[20:21], v44, v48, v[52:53]\n\t" I4) "v_mad_u64_u32 v[40:41], s[20:21], v44, v48, v[52:53]\n\t" I4 "v_mad_u64_u32 v[40:41], s[20:21], v44, v48, v[52:53]\n\t" I4 "v_mad_u64_u32 v[40:41], s[20:21], v44, v48, v[52:53]\n\t" I4)
+BKL(k_subco_chain, REP16("v_sub_co_u32_e64 v40, s[20:21], v44, v45\n\tv_subb_co_u32_e64 v41, s[22:23], v46, 0, s[24:25]\n\t") REP8("v_sub_co_u32_e64 v40, s[20:21], v44, v45\n\tv_subb_co_u32_e64 v41, s[22:23], v46, 0, s[24:25]\n\t") REP4("v_sub_co_u32_e64 v40, s[20:21], v44, v45\n\tv_subb_co_u32_e64 v41, s[22:23], v46, 0, s[24:25]\n\t") "v_sub_co_u32_e64 v40, s[20:21], v44, v45\n\tv_subb_co_u32_e64 v41, s[22:23], v46, 0, s[24:25]\n\t" "v_sub_co_u32_e64 v40, s[20:21], v44, v45\n\tv_subb_co_u32_e64 v41, s[22:23], v46, 0, s[24:25]\n\t" "v_sub_co_u32_e64 v40, s[20:21], v44, v45\n\tv_subb_co_u32_e64 v41, s[22:23], v46, 0, s[24:25]\n\t")
+
 struct Case {
     const char* name;
     void (*fn)(unsigned long long*, unsigned*);
@@ -152,7 +280,10 @@ int main(int argc, char** argv)
                                C(k_branch_taken, 2), C(k_branch_not, 2), C(k_cbranch_taken, 2), C(k_cvt_rcp, 2), C(k_ffbh, 1),
                                C(k_readlane, 2), C(k_salu, 1), C(k_valu_salu, 2),
                                C(k_sym_gap0, 65), C(k_sym_gap4, 69), C(k_sym_gap8, 73), C(k_sym_gap12, 77), C(k_sym_gap16, 81), C(k_sym_gap24, 89),
-                               C(k_sym_gap32, 97), C(k_sym_gap12_noatom, 76), C(k_sym_gap12_b64, 77), C(k_sym_gap0_b64, 65)};
+                               C(k_sym_gap32, 97), C(k_sym_gap12_noatom, 76), C(k_sym_gap12_b64, 77), C(k_sym_gap0_b64, 65),
+                               C(k_blk_a, 17), C(k_blk_u, 9), C(k_blk_c, 36), C(k_blk_auc, 62), C(k_loop_auc, 62), C(k_loop_add62, 62), C(k_loop_min3_62, 62),
+                               C(k_pat_84, 62), C(k_pat_884, 62), C(k_pat_844, 62), C(k_pat_8884, 62), C(k_pat_D62, 62),
+                               C(k_bank_same3, 62), C(k_bank_diff3, 62), C(k_bank_same2, 62), C(k_mad64_same, 62), C(k_subco_chain, 62)};
     printf("waves/workgroup %d, workgroups %d, %d copies per measurement\n", waves, wgs, REPS);
     for (auto& c : cases) {
         if (only && !strstr(c.name, only)) continue;
