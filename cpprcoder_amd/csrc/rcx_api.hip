@@ -624,6 +624,20 @@ int rcx_debug_stamps(unsigned long long* out16)
 }
 #endif
 
+int rcx_ctx_last_redo(rcx_ctx* c, uint64_t nblocks, uint64_t* count)
+{
+    if (!c || !count) return RCX_E_ARG;
+    *count = 0;
+    if (nblocks == 0 || !c->redo) return RCX_OK;
+    if (nblocks > c->redo_count) return RCX_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<u32> host(nblocks);
+    HIP_TRY(hipMemcpy(host.data(), c->redo, nblocks * sizeof(u32), hipMemcpyDeviceToHost));
+    for (u64 i = 0; i < nblocks; ++i) *count += host[i] != 0;
+    return RCX_OK;
+}
+
 int rcx_ctx_set_timing(rcx_ctx* c, int enabled)
 {
     if (!c) return RCX_E_ARG;

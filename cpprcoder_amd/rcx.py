@@ -24,7 +24,7 @@ EXPORTS = (
     "rcx_version", "rcx_status_string", "rcx_ctx_create", "rcx_ctx_destroy", "rcx_ctx_reserve", "rcx_ctx_sync_status",
     "rcx_block_count", "rcx_block_bound", "rcx_encode_bound", "rcx_encode_blocks_device", "rcx_decode_blocks_device",
     "rcx_encode_blocks", "rcx_decode_blocks", "rcx_stream_encode", "rcx_stream_decode", "rcx_ctx_set_timing",
-    "rcx_ctx_get_timing",
+    "rcx_ctx_get_timing", "rcx_ctx_last_redo",
 )
 
 
@@ -68,6 +68,7 @@ def lib() -> C.CDLL:
         L.rcx_stream_decode.argtypes = [vp, i32, vp, u64, vp, u64, C.POINTER(u64), C.POINTER(u32)]
         L.rcx_ctx_set_timing.restype, L.rcx_ctx_set_timing.argtypes = i32, [vp, i32]
         L.rcx_ctx_get_timing.restype, L.rcx_ctx_get_timing.argtypes = i32, [vp, C.POINTER(C.c_double), C.POINTER(u64), i32]
+        L.rcx_ctx_last_redo.restype, L.rcx_ctx_last_redo.argtypes = i32, [vp, u64, C.POINTER(u64)]
         _lib = L
     return _lib
 
@@ -198,6 +199,12 @@ class Context:
     # ---- per-kernel device time -------------------------------------------
     def set_timing(self, enabled: bool) -> None:
         _check(lib().rcx_ctx_set_timing(self._h, int(enabled)), "rcx_ctx_set_timing")
+
+    def last_redo(self, nblocks: int) -> int:
+        """Blocks of the last encode/decode call that the one-lane kernels had to take over (0 on ordinary data)."""
+        count = C.c_uint64(0)
+        _check(lib().rcx_ctx_last_redo(self._h, C.c_uint64(nblocks), C.byref(count)), "rcx_ctx_last_redo")
+        return int(count.value)
 
     def get_timing(self, reset: bool = True):
         ms = (C.c_double * T_COUNT)()

@@ -142,6 +142,12 @@ int rcx_stream_decode(rcx_ctx* ctx, int coder, const uint8_t* comp, uint64_t com
 /* Per-kernel device time of the calls made since the last reset, in milliseconds,
  * measured with HIP events on the stream the kernels ran on (off by default). */
 enum { RCX_T_ENCODE = 0, RCX_T_SCAN = 1, RCX_T_SCATTER = 2, RCX_T_DECODE = 3, RCX_T_COUNT = 4 };
+/* How many of the first `nblocks` blocks of the LAST rcx_encode_blocks* / rcx_decode_blocks* call on this
+ * context were handed to the one-lane kernels (the many-lane kernels mark, and do not finish, a block whose
+ * carry runs through more output bytes than they keep in LDS, or whose stream asks for a symbol past the
+ * table; results are the same either way).  Synchronises the device.  Diagnostic: 0 on ordinary data. */
+int rcx_ctx_last_redo(rcx_ctx* ctx, uint64_t nblocks, uint64_t* count);
+
 int rcx_ctx_set_timing(rcx_ctx* ctx, int enabled);
 /* Synchronises the events; ms[RCX_T_COUNT] = summed durations, launches[RCX_T_COUNT] = launch counts. */
 int rcx_ctx_get_timing(rcx_ctx* ctx, double* ms, uint64_t* launches, int reset);

@@ -211,11 +211,37 @@ def test_corrupt_payload_decodes_like_the_reference(ctx, oracle):
     payload, offsets = oracle.compact(big, big_sizes)
     back, st, _ = gpu_decode(ctx, payload, offsets, len(data), block)
     assert st == 0
+    assert ctx.last_redo(nblocks) >= nblocks // 6  # at least the blocks damaged at their first symbol
     for b in range(nblocks):
         assert np.array_equal(back[b * block:(b + 1) * block], want[b * block:(b + 1) * block]), f"block {b}"
         if b not in hit:
             assert np.array_equal(back[b * block:(b + 1) * block], data[b * block:(b + 1) * block])
     assert not np.array_equal(want, data)
+
+
+def test_carry_through_long_runs_of_ff(ctx, oracle):
+    """A carry through a held run of 0xFF bytes (cpprcoder.h:767-800).  Runs shorter than what the five-wave
+    encoder keeps in LDS are resolved there; longer ones make it hand the block to the one-lane kernel.  Either
+    way the stream is the reference's, and it decodes."""
+    import carry_runs
+    block = 4096
+    runs = [0, 3, 20, 30, 40, 70, 300, 0, 0, 45, 0, 1000]
+    parts = [carry_runs.carry_run_block(block, r, 100 + i) if r else workloads.uniform(block, 100 + i) for i, r in enumerate(runs)]
+    data = np.concatenate(parts)
+    payload, offsets, _ = gpu_encode(ctx, data, block)
+    redone = ctx.last_redo(len(runs))
+    slots, sizes = oracle.encode_blocks(data, block, threads=4)
+    assert_same_blocks(payload, offsets, slots, sizes)
+    assert redone >= sum(r > 64 for r in runs), redone   # those cannot have been resolved in the 32-byte margin
+    assert redone <= sum(r > 24 for r in runs), redone   # and short runs must not take the slow path
+    back, st, _ = gpu_decode(ctx, payload, offsets, len(data), block)
+    assert st == 0 and np.array_equal(back, data)
+    assert ctx.last_redo(len(runs)) == 0                  # a valid stream never takes the decoder's slow path
+    # ordinary data: nothing is handed over
+    plain = workloads.zipf(64 * 65536, 7)
+    p2, o2, _ = gpu_encode(ctx, plain, 65536)
+    assert ctx.last_redo(64) == 0
+    assert np.array_equal(gpu_decode(ctx, p2, o2, len(plain), 65536)[0], plain)
 
 
 def test_single_stream_semantics(ctx, oracle, golden):
