@@ -560,7 +560,7 @@ __global__ __launch_bounds__(RCX_MC_THREADS) void rcx_enc_mc_k(const u8* __restr
 //
 // find() (cpprcoder.h:1220-1242) in the scaled domain (see DecLane), without selects:
 //   x_k = low - U_k*t wraps past zero exactly for the bounds above low, so
-//     * the number of borrows, summed over the quad, is 16 - node,
+//     * the number of bounds that do NOT borrow, summed over the quad, is the node index,
 //     * the unsigned minimum of low and all x_k over the quad is low - cum(node)*t;
 //   round 2 is the same over the node's 16 counts, and the unsigned maximum of the x over the
 //   quad is the (wrapped) distance to the smallest bound above, so the new range count*t is
