@@ -274,6 +274,18 @@ struct EncLane {
         range <<= k8;
         return (moved & 0xFFFFFF00u) | (k8 >> 2) | carry;
     }
+    // the same with the divisor's fields passed separately (the addend as the 64-bit pair the multiply-add takes)
+    RCX_DEV u32 arith_q(u32 cum, u32 f, u32 mul, u32 shift, u64 add)
+    {
+        const u32 t = (u32)(((u64)range * mul + add) >> 32) >> (shift & 31u); // cpprcoder.h:703
+        const u32 moved = low + rcx_mul24(cum, t);                            // :706
+        const u32 carry = moved < low ? 1u : 0u;
+        range = rcx_mul24(f, t);                                              // :707
+        const u32 k8 = rcx_clz(range) & 0x18u;
+        low = moved << k8;
+        range <<= k8;
+        return (moved & 0xFFFFFF00u) | (k8 >> 2) | carry;
+    }
     RCX_DEV void emit(u32 rec)
     {
         const u32 k8 = (rec << 2) & 0x18u;

@@ -594,6 +594,8 @@ __global__ __launch_bounds__(RCX_MC_THREADS) void rcx_enc_mc_k(const u8* __restr
 typedef u32 RcxV4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) RcxV4 RcxLdsV4;
 typedef __attribute__((address_space(3))) u32 RcxLdsU32;
+typedef RcxV4 RcxDivQv;          // a staged divisor as four dwords: mul, shift (| total << 5), addend low, addend high
+typedef RcxLdsV4 RcxLdsDivQ;
 
 // divisor entry as the quad decoder stages it: the 64-bit addend is read as a register pair
 struct alignas(16) DivQ {
@@ -1064,7 +1066,8 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
 //
 // The writer does not store to global memory: scattered 4-byte stores under an EXEC mask were its most
 // expensive step.  Its words go to a per-block ring in LDS (one ds_write_b32 per symbol, to a dummy word
-// when nothing is due), and the lightest wave (model level 1) drains the rings once per chunk with 16-byte
+// when nothing is due), and the level-1 model wave drains the rings once per chunk with 16-byte (the leaf wave,
+// alone on its SIMD, looked like the better place and measured 9 % slower)
 // stores.  The ring keeps the newest RCX_OUT_MARGIN bytes back, so that a carry that runs off the writer's
 // registers (cpprcoder.h:767-781) is resolved in LDS; a run of 0xFF bytes longer than that margin cannot be,
 // and such a block is marked in `redo` and encoded again by rcx_enc_adaptive_k.
@@ -1159,24 +1162,33 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
             if (k >= 1 && k <= nchunks) {
                 const u32 i0 = (k - 1) * RCX_MC_CHUNK;
                 if ((i0 % RCX_STAGE) == 0) {
-                    stage[lane] = ahead;
+                    // staged with the 64-bit addend of the multiply-add as a register pair (see DivQ)
+                    DivQ q;
+                    q.mul = ahead.mul;
+                    q.st = ahead.shift;
+                    q.add = ahead.add;
+                    reinterpret_cast<DivQ*>(stage)[lane] = q;
                     ahead = divtab[i0 + RCX_STAGE + lane];
                 }
                 const U4* rs = ring + ((k - 1) & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
                 u32* ws2 = ring2 + ((k - 1) & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
-                const DivEntry* st = stage + (i0 % RCX_STAGE);
+                // the chunk's divisors through one vector base register and immediate offsets (a wave-uniform
+                // address would be rebuilt in a scalar register and moved over for every read)
+                u32 st_lds = (u32)reinterpret_cast<uintptr_t>(stage + (i0 % RCX_STAGE));
+                asm volatile("" : "+v"(st_lds));
+                const RcxLdsDivQ* st = reinterpret_cast<const RcxLdsDivQ*>(st_lds);
                 U4 e_next = rs[0];
-                DivEntry k_next = st[0];
+                RcxDivQv k_next = st[0];
 #pragma unroll
                 for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
                     const U4 e = e_next;
-                    const DivEntry kk = k_next;
+                    const RcxDivQv kk = k_next;
                     if (s + 1 < RCX_MC_CHUNK) {
                         e_next = rs[(s + 1) * RCX_LANES];
                         k_next = st[s + 1];
                     }
                     u32 rec = 0; // past the end of a short block: a record that does nothing
-                    if (FULL || i0 + s < len) rec = enc.arith(e.x + e.y + e.z, e.w, kk);
+                    if (FULL || i0 + s < len) rec = enc.arith_q(e.x + e.y + e.z, e.w, kk.x, kk.y, ((u64)kk.w << 32) | kk.z);
                     ws2[s * RCX_LANES] = rec;
                 }
             }
