@@ -129,19 +129,29 @@ struct Tree {
     }
 };
 
-// sum of the first p entries of a group, p in 0..3
+// Sum of the first p entries of a group and the p-th entry, p in 0..3.  Written with 0/1 factors instead of
+// compares: (p > 0) = min(p, 1), (p > 1) = p >> 1, (p > 2) = p & (p >> 1), and the counts are < 2^24, so each
+// term is one v_mad_u32_u24 -- no compare whose mask the next instruction has to wait two slots for.
+RCX_DEV u32 rcx_min1(u32 p)
+{
+#if defined(RCX_HOST_SIM)
+    return p < 1u ? p : 1u;
+#else
+    u32 m; // opaque to the compiler, which would turn "x * min(p, 1)" back into compare + select
+    asm("v_min_u32 %0, 1, %1" : "=v"(m) : "v"(p));
+    return m;
+#endif
+}
 RCX_DEV u32 rcx_pre4(const U4& g, u32 p)
 {
-    u32 r = (p > 0) ? g.x : 0;
-    r += (p > 1) ? g.y : 0;
-    r += (p > 2) ? g.z : 0;
-    return r;
+    const u32 m1 = rcx_min1(p), m2 = p >> 1, m3 = p & m2;
+    return rcx_mul24(g.x, m1) + rcx_mul24(g.y, m2) + rcx_mul24(g.z, m3);
 }
 RCX_DEV u32 rcx_sel4(const U4& g, u32 p)
 {
-    u32 lo = (p & 1) ? g.y : g.x;
-    u32 hi = (p & 1) ? g.w : g.z;
-    return (p & 2) ? hi : lo;
+    const u32 m1 = rcx_min1(p), m2 = p >> 1, m3 = p & m2;
+    // (sum of the first p + 1) - (sum of the first p)
+    return g.x + rcx_mul24(g.y, m1) + rcx_mul24(g.z, m2) + rcx_mul24(g.w, m3) - (rcx_mul24(g.x, m1) + rcx_mul24(g.y, m2) + rcx_mul24(g.z, m3));
 }
 
 // Add `extra` into the `count` payload bytes already stored, from the newest backwards
