@@ -347,13 +347,21 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
     int r = ensure_divtab(c, block);
     if (r != RCX_OK) return r;
     const bool quad = coder == RCX_CODER_ADAPTIVE && decode_lanes(c, nblocks) == 4;
-    if (quad && (r = ensure_redo(c, nblocks)) != RCX_OK) return r; // no-op after rcx_ctx_reserve
+    const bool squad = coder == RCX_CODER_STATIC && decode_lanes(c, nblocks) != 1;
+    if ((quad || squad) && (r = ensure_redo(c, nblocks)) != RCX_OK) return r; // no-op after rcx_ctx_reserve
     {
         Timed t(c, s, RCX_T_DECODE);
-        if (coder == RCX_CODER_STATIC) {
+        if (coder == RCX_CODER_STATIC && decode_lanes(c, nblocks) != 1) {
+            const u64 per_wg = RCX_QUAD_BLOCKS * RCX_QUAD_DEC_WAVES;
+            const u32 grid = (u32)((nblocks + per_wg - 1) / per_wg);
+            hipLaunchKernelGGL(rcx_dec_static_quad_k<RCX_QUAD_DEC_WAVES>, dim3(grid), dim3(64 * RCX_QUAD_DEC_WAVES), 0, s,
+                               static_cast<const u8*>(d_comp), d_offsets, nblocks, block, n, static_cast<u8*>(d_dst), c->status,
+                               c->redo);
+        } else if (coder == RCX_CODER_STATIC) {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_dec_static_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
-                               block, n, static_cast<u8*>(d_dst), c->status, static_cast<u32*>(nullptr));
+                               block, n, static_cast<u8*>(d_dst), c->status, static_cast<u32*>(nullptr),
+                               static_cast<const u32*>(nullptr));
         } else if (decode_lanes(c, nblocks) == 4) {
             if (wide_workgroups(c, nblocks)) {
                 const u64 per_wg = RCX_QUAD_BLOCKS * RCX_QUAD_DEC_WAVES;
@@ -393,6 +401,11 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
         hipLaunchKernelGGL(rcx_dec_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets,
                            nblocks, block, n, static_cast<u8*>(d_dst), c->divtab, c->status, static_cast<u32*>(nullptr),
                            static_cast<const u32*>(c->redo));
+    }
+    if (squad) { // the same for the static coder: a target past the table or a symbol of count 0
+        const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
+        hipLaunchKernelGGL(rcx_dec_static_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
+                           block, n, static_cast<u8*>(d_dst), c->status, static_cast<u32*>(nullptr), static_cast<const u32*>(c->redo));
     }
     return hipGetLastError() == hipSuccess ? RCX_OK : RCX_E_HIP;
 }
@@ -556,7 +569,7 @@ int rcx_stream_decode(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
         HIP_TRY(hipMemcpy(c->h_in, comp, comp_size, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->h_off, offs, sizeof(offs), hipMemcpyHostToDevice));
         hipLaunchKernelGGL(rcx_dec_static_k<true>, dim3(1), dim3(64), 0, nullptr, c->h_in, c->h_off, (u64)1, block, count, c->h_out,
-                           c->status, c->status + 2);
+                           c->status, c->status + 2, static_cast<const u32*>(nullptr));
         if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
         HIP_TRY(hipMemcpy(c->status_host, c->status, 4 * sizeof(u32), hipMemcpyDeviceToHost));
         const u32 short_at = c->status_host[2];

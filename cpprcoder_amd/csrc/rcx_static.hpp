@@ -140,12 +140,18 @@ __global__ __launch_bounds__(64) void rcx_enc_static_k(const u8* __restrict__ sr
 // track[0] = first symbol whose renormalisation ran out of input (cpprcoder.h:506-509), or 0xFFFFFFFF.
 template <bool STREAM>
 __global__ __launch_bounds__(64) void rcx_dec_static_k(const u8* __restrict__ comp, const u64* __restrict__ offsets, u64 nblocks,
-                                                       u32 block, u64 n, u8* __restrict__ dst, u32* status, u32* track)
+                                                       u32 block, u64 n, u8* __restrict__ dst, u32* status, u32* track,
+                                                       const u32* __restrict__ only)
 {
     __shared__ u32 lds[RCX_STATIC_LDS_DW + RCX_RING_DW * RCX_LANES];
     const u32 lane = threadIdx.x;
     const u64 blk = (u64)blockIdx.x * RCX_LANES + lane;
     bool live = blk < nblocks;
+    // second pass behind rcx_dec_static_quad_k: only the blocks it marked (none, on valid input)
+    if (only) {
+        live = live && only[blk] != 0;
+        if (!__any(live)) return;
+    }
     const u64 at = live ? blk * (u64)block : 0;
     u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
     StaticTable tab{lds + lane};
@@ -265,4 +271,241 @@ __global__ __launch_bounds__(64) void rcx_dec_static_k(const u8* __restrict__ co
     } else if (live && (bad || dec.taken() + (RCX_STATIC_HEADER - 3) > stream_len)) {
         rcx_flag(status, RCX_ST_CORRUPT, blk);
     }
+}
+
+// ===========================================================================
+// Static decode, 4 lanes per block: rcx_dec_quad_k's machinery (rcx_oct.hpp) with less to do per
+// symbol -- the table never changes.  The block's 256 cumulative counts cum[1..256] (cpprcoder.h:573-583)
+// sit in LDS as 16 nodes of 16 entries in the same bank-conflict-free table groups; lane j keeps the
+// upper bounds of its four nodes, cum[16(4j+1)] .. cum[16(4j+4)], in registers for the whole block.
+// find() (cpprcoder.h:521-535) counts the entries cum[1..255] that are <= low/t; in the scaled domain
+// (cum*t <= low: every product is <= total*t <= range < 2^32) that is round 1 = the node bounds that do not
+// borrow in low - bound*t, round 2 = the same over the node's 16 entries, read as they are (they are already
+// cumulative: no scan).  low - cum[c]*t is the unsigned minimum of the differences, and the new range
+// (cum[c+1] - cum[c])*t is minimum - maximum (mod 2^32), as in the adaptive decoder.  No update.
+// The reference normalises AFTER a symbol (cpprcoder.h:500-517); with range = 0xFFFFFFFF at the start that is
+// the same as normalising before the next one, plus once after the last.
+// A stream whose target runs past the table or that names a symbol of count 0 (damaged input) is marked in
+// `redo` and decoded by rcx_dec_static_k, which reports it the way the reference fails.
+// ===========================================================================
+#define RCX_SQUAD_LDS_BYTES (4 * RCX_QUAD_GROUP_BYTES + RCX_QUAD_BLOCKS * RCX_QUAD_RING_BYTES)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void rcx_dec_static_quad_k(const u8* __restrict__ comp, const u64* __restrict__ offsets,
+                                                                    u64 nblocks, u32 block, u64 n, u8* __restrict__ dst,
+                                                                    u32* status, u32* __restrict__ redo)
+{
+    __shared__ __attribute__((aligned(256))) u8 lds_all[WAVES * RCX_SQUAD_LDS_BYTES];
+    const u32 lane = threadIdx.x & 63u;
+    const u32 wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u8* lds = lds_all + wave_in_wg * RCX_SQUAD_LDS_BYTES;
+    const u32 j = lane & 3u, quad = lane >> 2;
+    const u64 blk = ((u64)blockIdx.x * WAVES + wave_in_wg) * RCX_QUAD_BLOCKS + quad;
+    bool live = blk < nblocks;
+    const u64 at = live ? blk * (u64)block : 0;
+    u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
+
+    const u32 group = 2u * (quad >> 3) + ((0x96u >> (quad & 7u)) & 1u), quarter = (quad & 7u) >> 1; // see rcx_dec_quad_k
+    u8* mine = lds + group * RCX_QUAD_GROUP_BYTES + quarter * 64;
+    U4* leaves = reinterpret_cast<U4*>(mine) + j;
+    U4* parked = reinterpret_cast<U4*>(mine + 16 * 256);
+    u32* block_ring = reinterpret_cast<u32*>(lds + 4 * RCX_QUAD_GROUP_BYTES + quad * RCX_QUAD_RING_BYTES);
+
+    QuadInput in;
+    u64 stream_len = 0;
+    u32 U1 = 1, U2 = 2, U3 = 3, U4_ = 4, total = 4;
+    if (live) {
+        const u64 s0 = offsets[blk], s1 = offsets[blk + 1];
+        stream_len = s1 - s0;
+        const u8* s = comp + s0;
+        // cpprcoder.h:474-493: at least the header, one more byte, then 5 bytes for the lead-in and low
+        bool good = s1 >= s0 && stream_len >= RCX_STATIC_HEADER + 5;
+        if (good) {
+            const u32 declared = (u32)s[0] | ((u32)s[1] << 8) | ((u32)s[2] << 16) | ((u32)s[3] << 24);
+            good = declared == len;
+        }
+        if (good) {
+            // cpprcoder.h:585-602 + :573-583: lane j takes the counts of symbols 64j .. 64j+63
+            const u8* cs = s + 4 + 128 * j;
+            u32 mysum = 0;
+            for (u32 i = 0; i < 64; ++i) mysum += (u32)cs[2 * i] | ((u32)cs[2 * i + 1] << 8);
+            u32 run = rcx_quad_excl_scan(mysum, (j & 1u) ? ~0u : 0u, (j & 2u) ? ~0u : 0u);
+            for (u32 i = 0; i < 64; ++i) {
+                run += (u32)cs[2 * i] | ((u32)cs[2 * i + 1] << 8);
+                // entry e = 64j + i + 1 = cum[e] lives in node (e-1)/16 at position (e-1)%16
+                reinterpret_cast<u32*>(mine + (4 * j + (i >> 4)) * 256)[i & 15u] = run;
+                if (i == 15) U1 = run;
+                if (i == 31) U2 = run;
+                if (i == 47) U3 = run;
+            }
+            U4_ = run;
+            total = rcx_dpp<0xFF>(U4_); // quad_perm [3,3,3,3]: cum[256]
+            good = total != 0;          // the reference would divide by zero
+        }
+        if (good) {
+            // QuadInput::begin expects 4 size bytes + 4 bytes of low; the static stream has its lead-in byte in
+            // between (low = bytes[1..4] after the header, cpprcoder.h:494-498): start it 3 bytes early
+            in.begin(s + RCX_STATIC_HEADER - 3, comp + s1, block_ring, parked + 3);
+            in.range = 0xFFFFFFFFu;
+        } else {
+            if (j == 0) rcx_flag(status, RCX_ST_CORRUPT, blk);
+            live = false;
+            len = 0;
+        }
+    }
+    if (!live) {
+        in.idle(comp, block_ring, parked + 3);
+        U1 = 1, U2 = 2, U3 = 3, U4_ = 4, total = 4;
+        U4 v;
+        v.x = v.y = v.z = v.w = 4;
+        for (u32 q = 0; q < 16; ++q) leaves[q * 16] = v;
+    }
+    {
+        U4 v; // the scratch row ("node 16", reached only by a target past the table)
+        v.x = v.y = v.z = v.w = 0;
+        leaves[16 * 16] = v;
+    }
+    const DivEntry k = rcx_make_div_entry(total);
+    const u64 kadd = k.add;
+
+    const u32 maxlen = rcx_wave_max(len);
+    const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+    u8* out = dst + at;
+    const bool leader = live && j == 0;
+    const u32 leaves_lds = (u32)reinterpret_cast<uintptr_t>(leaves);
+    u32 worst_node = 0;            // 16 = a target past the table
+    u32 least_range = 0xFFFFFFFFu; // 0 = a symbol of count 0
+
+#define RCX_QP1 "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define RCX_QP2 "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    // One symbol (instruction sequences as in rcx_dec_quad_k: no compare result or DPP source is used before two
+    // other instructions have been issued).  Every lane of the quad ORs the symbol into WORD at bit SHIFT.
+#define RCX_SQUAD_SYMBOL(WORD, SHIFT)                                                                      \
+    {                                                                                                      \
+        const u32 k8_ = rcx_clz(in.range) & 0x18u; /* cpprcoder.h:511-516, for the previous symbol */      \
+        in.low = (u32)((((u64)in.low << 32) | in.n4) << k8_ >> 32);                                        \
+        in.range <<= k8_;                                                                                  \
+        const u32 t_ = (u32)(((u64)in.range * k.mul + kadd) >> 32) >> (k.shift & 31u); /* :502 */          \
+        const u32 a1_ = U1 * t_, a2_ = U2 * t_, a3_ = U3 * t_, a4_ = U4_ * t_;                             \
+        u32 node_, rem_, ro_, la_, x1_, x2_, x3_, x4_;                                                     \
+        u64 c1_, c2_, c3_, c4_;                                                                            \
+        asm volatile("v_sub_co_u32_e64 %[x1], %[c1], %[low], %[a1]\n\t"                                    \
+                     "v_sub_co_u32_e64 %[x2], %[c2], %[low], %[a2]\n\t"                                    \
+                     "v_sub_co_u32_e64 %[x3], %[c3], %[low], %[a3]\n\t"                                    \
+                     "v_sub_co_u32_e64 %[x4], %[c4], %[low], %[a4]\n\t"                                    \
+                     "v_subb_co_u32_e64 %[nd], %[c1], 4, 0, %[c1]\n\t"                                     \
+                     "v_min3_u32 %[rm], %[x1], %[x2], %[x3]\n\t"                                           \
+                     "v_subb_co_u32_e64 %[nd], %[c2], %[nd], 0, %[c2]\n\t"                                 \
+                     "v_min3_u32 %[rm], %[rm], %[x4], %[low]\n\t"                                          \
+                     "v_subb_co_u32_e64 %[nd], %[c3], %[nd], 0, %[c3]\n\t"                                 \
+                     "v_subb_co_u32_e64 %[nd], %[c4], %[nd], 0, %[c4]\n\t"                                 \
+                     "v_min_u32_dpp %[rm], %[rm], %[rm] " RCX_QP1                                          \
+                     "v_add_u32 %[bp], %[bp], %[k8]\n\t"                                                   \
+                     "v_add_u32_dpp %[nd], %[nd], %[nd] " RCX_QP1                                          \
+                     "v_min_u32_dpp %[rm], %[rm], %[rm] " RCX_QP2                                          \
+                     "v_bfe_u32 %[ro], %[bp], 5, 5\n\t"                                                    \
+                     "v_add_u32_dpp %[nd], %[nd], %[nd] " RCX_QP2                                          \
+                     "v_lshl_add_u32 %[la], %[nd], 8, %[lvb]"                                              \
+                     : [nd] "=&v"(node_), [rm] "=&v"(rem_), [ro] "=&v"(ro_), [bp] "+v"(in.bp8), [la] "=&v"(la_), \
+                       [x1] "=&v"(x1_), [x2] "=&v"(x2_), [x3] "=&v"(x3_), [x4] "=&v"(x4_),                 \
+                       [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_), [c4] "=&s"(c4_)                  \
+                     : [low] "v"(in.low), [a1] "v"(a1_), [a2] "v"(a2_), [a3] "v"(a3_), [a4] "v"(a4_),      \
+                       [k8] "v"(k8_), [lvb] "v"(leaves_lds));                                              \
+        const RcxV4 l_ = *reinterpret_cast<const RcxLdsV4*>(la_);                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        {                                                                                                  \
+            const u32* at_ = in.ring + ro_; /* for the next symbol: never waited for */                    \
+            in.w0 = at_[0];                                                                                \
+            in.w1 = at_[1];                                                                                \
+        }                                                                                                  \
+        worst_node = worst_node > node_ ? worst_node : node_;                                              \
+        const u32 q1_ = l_.x * t_, q2_ = l_.y * t_, q3_ = l_.z * t_, q4_ = l_.w * t_;                      \
+        u32 lo_, rg_, nb_, hi_, y1_, y2_, y3_, y4_;                                                        \
+        asm volatile("v_sub_co_u32_e64 %[y1], %[c1], %[low], %[q1]\n\t"                                    \
+                     "v_sub_co_u32_e64 %[y2], %[c2], %[low], %[q2]\n\t"                                    \
+                     "v_sub_co_u32_e64 %[y3], %[c3], %[low], %[q3]\n\t"                                    \
+                     "v_sub_co_u32_e64 %[y4], %[c4], %[low], %[q4]\n\t"                                    \
+                     "v_subb_co_u32_e64 %[nb], %[c1], 4, 0, %[c1]\n\t"                                     \
+                     "v_min3_u32 %[lo], %[y1], %[y2], %[y3]\n\t"                                           \
+                     "v_subb_co_u32_e64 %[nb], %[c2], %[nb], 0, %[c2]\n\t"                                 \
+                     "v_max3_u32 %[hi], %[y1], %[y2], %[y3]\n\t"                                           \
+                     "v_subb_co_u32_e64 %[nb], %[c3], %[nb], 0, %[c3]\n\t"                                 \
+                     "v_min3_u32 %[lo], %[lo], %[y4], %[rem]\n\t"                                          \
+                     "v_subb_co_u32_e64 %[nb], %[c4], %[nb], 0, %[c4]\n\t"                                 \
+                     "v_max_u32 %[hi], %[hi], %[y4]\n\t"                                                   \
+                     "v_min_u32_dpp %[lo], %[lo], %[lo] " RCX_QP1                                          \
+                     "v_add_u32_dpp %[nb], %[nb], %[nb] " RCX_QP1                                          \
+                     "v_max_u32_dpp %[hi], %[hi], %[hi] " RCX_QP1                                          \
+                     "v_min_u32_dpp %[lo], %[lo], %[lo] " RCX_QP2                                          \
+                     "v_add_u32_dpp %[nb], %[nb], %[nb] " RCX_QP2                                          \
+                     "v_max_u32_dpp %[hi], %[hi], %[hi] " RCX_QP2                                          \
+                     "v_alignbit_b32 %[n4], %[w1], %[w0], %[bp]\n\t" /* the 4 bytes at bp8 ... */           \
+                     "v_sub_u32 %[rg], %[lo], %[hi]\n\t"                                                   \
+                     "v_lshl_add_u32 %[nb], %[nd], 4, %[nb]\n\t"     /* the symbol, in all four lanes */    \
+                     "v_perm_b32 %[n4], %[n4], %[n4], %[swap]\n\t"   /* ... first one on top */            \
+                     "v_lshl_or_b32 %[word], %[nb], %[sh], %[word]"                                        \
+                     : [lo] "=&v"(lo_), [rg] "=&v"(rg_), [nb] "=&v"(nb_), [hi] "=&v"(hi_), [y1] "=&v"(y1_), \
+                       [y2] "=&v"(y2_), [y3] "=&v"(y3_), [y4] "=&v"(y4_), [c1] "=&s"(c1_), [c2] "=&s"(c2_),  \
+                       [c3] "=&s"(c3_), [c4] "=&s"(c4_), [word] "+v"(WORD), [n4] "=&v"(in.n4)              \
+                     : [low] "v"(in.low), [q1] "v"(q1_), [q2] "v"(q2_), [q3] "v"(q3_), [q4] "v"(q4_),      \
+                       [rem] "v"(rem_), [nd] "v"(node_), [sh] "n"(SHIFT), [w0] "v"(in.w0), [w1] "v"(in.w1), \
+                       [bp] "v"(in.bp8), [swap] "s"(0x00010203u));                                         \
+        in.low = lo_;   /* :504 */                                                                         \
+        in.range = rg_; /* :505 */                                                                         \
+        least_range = least_range < rg_ ? least_range : rg_;                                               \
+    }
+
+    if (full) {
+        U4 o_last;
+        o_last.x = o_last.y = o_last.z = o_last.w = 0;
+        for (u32 i0 = 0; i0 < maxlen; i0 += 16) {
+            in.topup();
+            const u32 g = (i0 >> 4) & 3u;
+            if (g == 0 && i0 != 0 && leader) { // see rcx_dec_quad_k: the stores follow the top-up
+                U4* o4 = reinterpret_cast<U4*>(out + (i0 - 64));
+                const U4 p0 = parked[0], p1 = parked[1], p2 = parked[2];
+                o4[0] = p0;
+                o4[1] = p1;
+                o4[2] = p2;
+                o4[3] = o_last;
+            }
+            u32 w0_ = 0, w1_ = 0, w2_ = 0, w3_ = 0;
+            RCX_SQUAD_SYMBOL(w0_, 0) RCX_SQUAD_SYMBOL(w0_, 8) RCX_SQUAD_SYMBOL(w0_, 16) RCX_SQUAD_SYMBOL(w0_, 24)
+            RCX_SQUAD_SYMBOL(w1_, 0) RCX_SQUAD_SYMBOL(w1_, 8) RCX_SQUAD_SYMBOL(w1_, 16) RCX_SQUAD_SYMBOL(w1_, 24)
+            RCX_SQUAD_SYMBOL(w2_, 0) RCX_SQUAD_SYMBOL(w2_, 8) RCX_SQUAD_SYMBOL(w2_, 16) RCX_SQUAD_SYMBOL(w2_, 24)
+            RCX_SQUAD_SYMBOL(w3_, 0) RCX_SQUAD_SYMBOL(w3_, 8) RCX_SQUAD_SYMBOL(w3_, 16) RCX_SQUAD_SYMBOL(w3_, 24)
+            U4 o;
+            o.x = w0_;
+            o.y = w1_;
+            o.z = w2_;
+            o.w = w3_;
+            if (g == 3) o_last = o;
+            else parked[g] = o;
+        }
+        if (leader && maxlen != 0) {
+            const u32 groups = ((maxlen - 1) >> 4 & 3u) + 1;
+            U4* o4 = reinterpret_cast<U4*>(out + ((maxlen - 1) & ~63u));
+            o4[0] = parked[0];
+            if (groups > 1) o4[1] = parked[1];
+            if (groups > 2) o4[2] = parked[2];
+            if (groups > 3) o4[3] = o_last;
+        }
+    } else {
+        for (u32 i = 0; i < maxlen; ++i) {
+            if ((i & 15u) == 0) in.topup();
+            if (i < len) { // the 4 lanes of a quad agree
+                u32 sym = 0;
+                RCX_SQUAD_SYMBOL(sym, 0);
+                if (leader) out[i] = (u8)sym;
+            }
+        }
+    }
+#undef RCX_SQUAD_SYMBOL
+#undef RCX_QP1
+#undef RCX_QP2
+    // the normalisation after the last symbol (it decides whether the input was long enough, cpprcoder.h:506-509)
+    in.bp8 += rcx_clz(in.range) & 0x18u;
+    const bool marked = live && (worst_node >= 16u || least_range == 0);
+    if (leader && !marked && in.taken() + (RCX_STATIC_HEADER - 3) > stream_len) rcx_flag(status, RCX_ST_CORRUPT, blk);
+    if (leader) redo[blk] = marked ? 1u : 0u;
+    else if (j == 0 && blk < nblocks) redo[blk] = 0;
 }
