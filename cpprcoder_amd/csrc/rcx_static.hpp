@@ -1,4 +1,6 @@
-// rcx_static.hpp -- the static (two-pass) range coder RangeEncoder<T> on gfx950, one lane per block.
+// rcx_static.hpp -- the static (two-pass) range coder RangeEncoder<T> on gfx950: one lane per block
+// (rcx_enc_static_k, rcx_dec_static_k), and the many-wave / four-lane kernels built on rcx_oct.hpp's machinery
+// (rcx_enc_static3_k, rcx_dec_static_quad_k).
 //
 // Reference: cpprcoder.h:321-619.  Stream of one block:
 //   [u32 LE n][256 x u16 LE counts][0x00 lead-in][payload ...][u32 BE low]      (516-byte header, :331)
@@ -41,12 +43,18 @@ struct StaticTable {
 // Static encode, pass 1 (scan + scatter are shared with the adaptive coder)
 // ===========================================================================
 __global__ __launch_bounds__(64) void rcx_enc_static_k(const u8* __restrict__ src, u64 n, u32 block, u64 nblocks,
-                                                       u8* __restrict__ slots, u64 slot, u32* __restrict__ sizes, u32* status)
+                                                       u8* __restrict__ slots, u64 slot, u32* __restrict__ sizes, u32* status,
+                                                       const u32* __restrict__ only)
 {
     __shared__ u32 lds[RCX_STATIC_LDS_DW];
     const u32 lane = threadIdx.x;
     const u64 blk = (u64)blockIdx.x * RCX_LANES + lane;
-    const bool live = blk < nblocks;
+    bool live = blk < nblocks;
+    // second pass behind rcx_enc_static3_k: only the blocks it marked (none, on ordinary data)
+    if (only) {
+        live = live && only[blk] != 0;
+        if (!__any(live)) return;
+    }
     const u64 at = live ? blk * (u64)block : 0;
     const u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
     const u8* in = src + at;
@@ -130,6 +138,226 @@ __global__ __launch_bounds__(64) void rcx_enc_static_k(const u8* __restrict__ sr
         const u32 bytes = enc.finish() + (RCX_STATIC_HEADER - 4);
         sizes[blk] = enc.overflow ? (u32)slot : bytes;
         if (enc.overflow) rcx_flag(status, RCX_ST_CAPACITY, blk);
+    }
+}
+
+// ===========================================================================
+// Static encode, pass 1, three waves per 64 blocks: the five-wave adaptive encoder (rcx_enc_mc5_k, rcx_oct.hpp)
+// without its model waves -- the table does not change while coding.  wave 0 = arithmetic (EncLane::arith with
+// full 32-bit multiplies), wave 1 = writer (StagedWriter: words through LDS rings), wave 2 = table lookups for
+// the next chunk + the drain of the rings.  The histogram (cpprcoder.h:543-571) is counted by all three waves
+// with LDS atomics for the first 65535 symbols of a block, where its 16-bit squeeze cannot fire.
+// A carry through more output bytes than the rings keep back marks the block in `redo` for rcx_enc_static_k.
+// ===========================================================================
+#define RCX_ST3_THREADS 192
+#define RCX_ST3_LDS_DW (RCX_STATIC_LDS_DW + 4 * RCX_MC_RING_U4 + RCX_MC5_RING2_DW + RCX_LANES + RCX_MC5_OUT_DW)
+
+template <bool FULL>
+__device__ __forceinline__ void rcx_static3_pipeline(u32 wave, u32 lane, u32 len, u32 nchunks, const u8* in, const StaticTable& tab,
+                                                     U4* ring, u32* ring2, EncLane& enc, const DivEntry& kdiv, StagedWriter& wr,
+                                                     u32* out_pos, u32& drained, u8* payload, u32 cap, bool live)
+{
+    U4 piece_ahead;
+    piece_ahead.x = piece_ahead.y = piece_ahead.z = piece_ahead.w = 0;
+    if (FULL && wave == 2 && nchunks > 0) piece_ahead = *reinterpret_cast<const U4*>(in);
+    for (u32 k = 0; k <= nchunks + 1; ++k) {
+        if (wave == 0) {
+            // ---- arithmetic: chunk k-1 ----
+            if (k >= 1 && k <= nchunks) {
+                const u32 i0 = (k - 1) * RCX_MC_CHUNK;
+                const U4* rs = ring + ((k - 1) & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
+                u32* ws2 = ring2 + ((k - 1) & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
+                U4 e_next = rs[0];
+#pragma unroll
+                for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
+                    const U4 e = e_next;
+                    if (s + 1 < RCX_MC_CHUNK) e_next = rs[(s + 1) * RCX_LANES];
+                    u32 rec = 0;
+                    if (FULL || i0 + s < len) rec = enc.template arith<true>(e.x, e.w, kdiv); // cpprcoder.h:402-408
+                    ws2[s * RCX_LANES] = rec;
+                }
+            }
+        } else if (wave == 1) {
+            // ---- writer: chunk k-2 ----
+            if (k >= 2) {
+                const u32* rs2 = ring2 + ((k - 2) & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
+                u32 r_next = rs2[0];
+                wr.safe_from = wr.pos > RCX_OUT_MARGIN ? wr.pos - RCX_OUT_MARGIN : 0u;
+#pragma unroll
+                for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
+                    const u32 rec = r_next;
+                    if (s + 1 < RCX_MC_CHUNK) r_next = rs2[(s + 1) * RCX_LANES];
+                    wr.emit(rec);
+                }
+                out_pos[lane] = wr.pos;
+            }
+        } else {
+            // ---- drain (see rcx_mc5_pipeline) ----
+            {
+                const u32 p = out_pos[lane];
+                const u32 limit = p > RCX_OUT_MARGIN ? (p - RCX_OUT_MARGIN) & ~15u : 0u;
+                while (__any(live && drained + 16 <= limit && drained + 16 <= cap)) {
+                    const bool go = live && drained + 16 <= limit && drained + 16 <= cap;
+                    if (go) {
+                        const u32* w = wr.ring_lane;
+                        const u32 w0 = drained >> 2;
+                        RcxU4Unaligned piece;
+                        piece.x = w[((w0 + 0) % RCX_OUT_RING_WORDS) * RCX_LANES];
+                        piece.y = w[((w0 + 1) % RCX_OUT_RING_WORDS) * RCX_LANES];
+                        piece.z = w[((w0 + 2) % RCX_OUT_RING_WORDS) * RCX_LANES];
+                        piece.w = w[((w0 + 3) % RCX_OUT_RING_WORDS) * RCX_LANES];
+                        *reinterpret_cast<RcxU4Unaligned*>(payload + drained) = piece;
+                        drained += 16;
+                    }
+                }
+            }
+            // ---- lookups: chunk k ----
+            if (k < nchunks) {
+                const u32 i0 = k * RCX_MC_CHUNK;
+                U4* ws = ring + (k & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
+                U4 piece;
+                if (FULL) {
+                    piece = piece_ahead;
+                    if (k + 1 < nchunks) piece_ahead = *reinterpret_cast<const U4*>(in + i0 + RCX_MC_CHUNK);
+                } else {
+                    u32 w[4] = {0, 0, 0, 0};
+                    for (u32 s = 0; s < RCX_MC_CHUNK; ++s)
+                        if (i0 + s < len) w[s >> 2] |= (u32)in[i0 + s] << (8 * (s & 3));
+                    piece.x = w[0];
+                    piece.y = w[1];
+                    piece.z = w[2];
+                    piece.w = w[3];
+                }
+                u32 b = rcx_byte_of(piece, 0);
+                u32 lo = tab.get(b), hi = tab.get(b + 1);
+#pragma unroll
+                for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
+                    const u32 lo_s = lo, hi_s = hi;
+                    if (s + 1 < RCX_MC_CHUNK) {
+                        b = rcx_byte_of(piece, s + 1);
+                        lo = tab.get(b);
+                        hi = tab.get(b + 1);
+                    }
+                    u32* e = reinterpret_cast<u32*>(&ws[s * RCX_LANES]);
+                    e[0] = lo_s;        // cum
+                    e[3] = hi_s - lo_s; // count
+                }
+            }
+        }
+        rcx_lds_barrier();
+    }
+}
+
+__global__ __launch_bounds__(RCX_ST3_THREADS) void rcx_enc_static3_k(const u8* __restrict__ src, u64 n, u32 block, u64 nblocks,
+                                                                    u8* __restrict__ slots, u64 slot, u32* __restrict__ sizes,
+                                                                    u32* status, u32* __restrict__ redo)
+{
+    __shared__ __attribute__((aligned(16))) u32 lds[RCX_ST3_LDS_DW];
+    const u32 lane = threadIdx.x & 63u;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u64 blk = (u64)blockIdx.x * RCX_LANES + lane;
+    const bool live = blk < nblocks;
+    const u64 at = live ? blk * (u64)block : 0;
+    const u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
+    const u8* in = src + at;
+    StaticTable tab{lds + lane};
+    U4* ring = reinterpret_cast<U4*>(lds + RCX_STATIC_LDS_DW); // 16-byte aligned: RCX_STATIC_LDS_DW = 257 * 64 dwords
+    u32* ring2 = reinterpret_cast<u32*>(ring + RCX_MC_RING_U4);
+    u32* final_low = ring2 + RCX_MC5_RING2_DW;
+    u32* out_ring = final_low + RCX_LANES;
+    u32* out_dummy = out_ring + RCX_OUT_RING_WORDS * RCX_LANES;
+    u32* out_pos = out_dummy + RCX_LANES;
+    u32* out_drained = out_pos + RCX_LANES;
+
+    const u32 maxlen = rcx_wave_max(len);
+    const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+    const u32 nchunks = (maxlen + RCX_MC_CHUNK - 1) / RCX_MC_CHUNK;
+
+    // ---- count(), cpprcoder.h:543-571 ----
+    for (u32 i = wave; i <= 256; i += 3) tab.set(i, 0);
+    {
+        U4 z; // the ring entries' two middle dwords stay 0: the arithmetic wave adds x + y + z
+        z.x = z.y = z.z = z.w = 0;
+        for (u32 i = wave; i < 2 * RCX_MC_CHUNK; i += 3) ring[i * RCX_LANES + lane] = z;
+    }
+    rcx_lds_barrier();
+    // a count can only be 0xFFFF before its increment once 65535 earlier symbols exist: no squeeze test before
+    const u32 easy = maxlen < 65535u ? maxlen : 65535u;
+    const u32 easy16 = full ? easy & ~15u : 0u;
+    for (u32 i = 16 * wave; i < easy16; i += 48) {
+        const U4 piece = *reinterpret_cast<const U4*>(in + i);
+#pragma unroll
+        for (u32 s = 0; s < 16; ++s) tab.inc(rcx_byte_of(piece, s));
+    }
+    rcx_lds_barrier();
+    if (wave == 0) {
+        for (u32 i = easy16; i < easy; ++i)
+            if (i < len) tab.inc(in[i]);
+        for (u32 i = easy; i < maxlen; ++i) {
+            if (i < len) {
+                const u32 b = in[i];
+                if (tab.get(b) >= 0xFFFFu) { // :549-555: every non-zero count becomes (c >> 1) | 1
+                    for (u32 q = 0; q < 256; ++q) {
+                        const u32 c = tab.get(q);
+                        if (c > 0) tab.set(q, (c >> 1) | 1u);
+                    }
+                }
+                tab.set(b, tab.get(b) + 1);
+            }
+        }
+    }
+    rcx_lds_barrier();
+
+    // ---- header: u32 LE n + 256 u16 counts (cpprcoder.h:386-397, :604-619) ----
+    u8* wave_slots = slots + (u64)blockIdx.x * RCX_LANES * slot;
+    EncLane enc;
+    enc.idle(wave_slots);
+    StagedWriter wr;
+    wr.begin(out_ring, out_dummy, lane);
+    u32 drained = 0;
+    if (wave == 1) {
+        if (live) {
+            enc.begin(wave_slots, lane * (u32)slot, (u32)slot, len);
+            u32* hdr = reinterpret_cast<u32*>(wave_slots + lane * (u32)slot + 4);
+            for (u32 i = 0; i < 256; i += 2) hdr[i >> 1] = (tab.get(i) & 0xFFFFu) | (tab.get(i + 1) << 16);
+            enc.off += RCX_STATIC_HEADER - 4;
+            enc.cap -= RCX_STATIC_HEADER - 4;
+        }
+        out_pos[lane] = 0;
+    }
+    rcx_lds_barrier();
+    if (wave == 2) (void)tab.accumulate(); // cpprcoder.h:573-583; entry 256 = total
+    rcx_lds_barrier();
+    const u32 total = tab.get(256);
+    const DivEntry k = rcx_make_div_entry(total ? total : 1u);
+    enc.range = 0xFFFFFFFFu; // cpprcoder.h:382
+
+    u8* payload = wave_slots + (u64)lane * slot + RCX_STATIC_HEADER;
+    const u32 cap = (((u32)slot - 4) & ~3u) - (RCX_STATIC_HEADER - 4);
+    if (full) rcx_static3_pipeline<true>(wave, lane, len, nchunks, in, tab, ring, ring2, enc, k, wr, out_pos, drained, payload, cap, live);
+    else rcx_static3_pipeline<false>(wave, lane, len, nchunks, in, tab, ring, ring2, enc, k, wr, out_pos, drained, payload, cap, live);
+
+    if (wave == 0) final_low[lane] = enc.low;
+    if (wave == 2) {
+        out_drained[lane] = drained;
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+    }
+    rcx_lds_barrier();
+    if (wave == 1 && live) {
+        u32 at2 = out_drained[lane];
+        const u32 end = wr.pos < cap ? wr.pos : cap;
+        for (; at2 < end; at2 += 4) *reinterpret_cast<u32*>(payload + at2) = wr.ring_lane[((at2 >> 2) % RCX_OUT_RING_WORDS) * RCX_LANES];
+        enc.low = final_low[lane];
+        enc.acc = wr.acc;
+        enc.nacc8 = wr.nacc8;
+        enc.pos = wr.pos;
+        if (enc.low == 0xFFFFFFFFu) enc.acc += 1; // cpprcoder.h:439-443
+        const u32 bytes = enc.finish() + (RCX_STATIC_HEADER - 4);
+        sizes[blk] = enc.overflow ? (u32)slot : bytes;
+        if (enc.overflow) rcx_flag(status, RCX_ST_CAPACITY, blk);
+        redo[blk] = (wr.redo != 0 && !enc.overflow) ? 1u : 0u;
+    } else if (wave == 1 && blk < nblocks) {
+        redo[blk] = 0;
     }
 }
 

@@ -51,3 +51,46 @@ def carry_run_block(n: int, run_len: int, seed: int) -> np.ndarray:
         out.append(c)
     assert done, "no carry run found: try another seed"
     return np.array(out, np.uint8)
+
+
+def carry_run_block_static(n: int, run_len: int, seed: int) -> np.ndarray:
+    """The same for the static coder (cpprcoder.h:400-436: fixed table, range starts at 0xFFFFFFFF).  The block
+    uses every byte value n / 256 times, so the table is known before the symbols are chosen."""
+    assert n % 256 == 0 and n // 256 < 0xFFFF
+    rs = np.random.RandomState(seed)
+    per = n // 256
+    left = [per] * 256
+    total = n
+    low, rng = 0, 0xFFFFFFFF
+    out = []
+    held = 0
+    done = False
+    while len(out) < n:
+        t = rng // total
+        c = None
+        if not done and low + total * t > M:
+            for s in range(256):
+                lo_s, hi_s = low + s * per * t, low + (s + 1) * per * t
+                if held < run_len and lo_s < M <= hi_s and left[s]:
+                    c = s
+                    break
+                if held >= run_len and lo_s >= M and left[s]:
+                    c = s
+                    done = True
+                    break
+        if c is None:
+            pool = [s for s in range(256) if left[s]]
+            c = pool[int(rs.randint(len(pool)))]
+            if not done:
+                held = 0
+        left[c] -= 1
+        low = (low + c * per * t) % M
+        rng = per * t
+        while rng < (1 << 24):
+            if (low >> 24) == 0xFF:
+                held += 1
+            low = (low << 8) % M
+            rng <<= 8
+        out.append(c)
+    assert done, "no carry run found: try another seed"
+    return np.array(out, np.uint8)

@@ -244,6 +244,31 @@ def test_carry_through_long_runs_of_ff(ctx, oracle):
     assert np.array_equal(gpu_decode(ctx, p2, o2, len(plain), 65536)[0], plain)
 
 
+def test_static_carry_through_long_runs_of_ff(ctx, oracle):
+    """The same for the static coder's three-wave encoder (rcx_enc_static3_k) and its second pass."""
+    import carry_runs
+    block = 8192
+
+    def make(run, i):
+        for seed in range(50):
+            try:
+                return carry_runs.carry_run_block_static(block, run, 1000 * i + seed)
+            except AssertionError:
+                pass
+        raise RuntimeError("no carry run found")
+
+    runs = [0, 5, 20, 60, 100, 0, 45]
+    parts = [make(r, i) if r else workloads.uniform(block, 300 + i) for i, r in enumerate(runs)]
+    data = np.concatenate(parts)
+    payload, offsets, _ = gpu_encode(ctx, data, block, coder=1)
+    redone = ctx.last_redo(len(runs))
+    slots, sizes = oracle.encode_blocks(data, block, coder=1, threads=4)
+    assert_same_blocks(payload, offsets, slots, sizes)
+    assert sum(r > 64 for r in runs) <= redone <= sum(r > 24 for r in runs), redone
+    back, st, _ = gpu_decode(ctx, payload, offsets, len(data), block, coder=1)
+    assert st == 0 and np.array_equal(back, data) and ctx.last_redo(len(runs)) == 0
+
+
 def test_single_stream_semantics(ctx, oracle, golden):
     """rcx_stream_encode / rcx_stream_decode == the reference's initialize+encode / initialize+decode
     on a MemoryStream of the given capacity (cpprcoder.h:678-720, 859-924, 1047-1054)."""
@@ -402,6 +427,18 @@ def test_every_kernel_variant_is_bit_identical(oracle):
                     assert np.array_equal(payload, ref_payload) and np.array_equal(offsets, ref_offsets), (block, enc)
                     back, st, _ = gpu_decode(c, payload, offsets, len(data), block)
                     assert st == 0 and np.array_equal(back, data), (block, dec)
+                    c.close()
+            # static coder: one-wave / three-wave encoder x one-lane / four-lane decoder
+            s_slots, s_sizes = oracle.encode_blocks(data, block, coder=1, threads=8)
+            s_payload, s_offsets = oracle.compact(s_slots, s_sizes)
+            for enc in ("0", "3"):
+                for dec in ("1", "4"):
+                    os.environ["RCX_ENC_VARIANT"], os.environ["RCX_LANES_PER_BLOCK"] = enc, dec
+                    c = rcx.Context(0)
+                    payload, offsets, _ = gpu_encode(c, data, block, coder=1)
+                    assert np.array_equal(payload, s_payload) and np.array_equal(offsets, s_offsets), ("static", block, enc)
+                    back, st, _ = gpu_decode(c, payload, offsets, len(data), block, coder=1)
+                    assert st == 0 and np.array_equal(back, data), ("static", block, dec)
                     c.close()
     finally:
         for k, v in saved.items():
