@@ -83,7 +83,21 @@ def cpu_baseline(name: str, seed: int, sample_bytes: int):
     }
 
 
+# The contract is ONE line on stdout.  RCCL prints a version banner to stdout when a communicator is created
+# (and other libraries may chat as well): everything written to file descriptor 1 during the run goes to stderr,
+# and the JSON line is written to the real stdout at the end.
+_REAL_STDOUT = 1
+
+
+def _stdout_to_stderr() -> None:
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+
+
 def main() -> None:
+    _stdout_to_stderr()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -245,7 +259,7 @@ def main() -> None:
                 line["gpu_over_cpu"] = round(line["value"] / cb["value"], 1)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
-        print(json.dumps(line), flush=True)
+        os.write(_REAL_STDOUT, (json.dumps(line) + "\n").encode())
 
     ctx.close()
     if exchange:
