@@ -140,23 +140,34 @@ def main() -> None:
     ctx = rcx.Context(local)
     ctx.reserve(n, block)
     bound = rcx.encode_bound(n, block)
-    comp = torch.empty(bound + 256, dtype=torch.uint8, device=device)  # +256: the exchange pads segments to 256 B
-    offs = torch.zeros(nblocks + 1, dtype=torch.int64, device=device)
+    # Two compressed buffers: with the exchange on, step i+1 encodes into the other one while the allgatherv of
+    # step i is still reading this one (the exchange of a step overlaps its own decode AND the next step's encode).
+    nbuf = 2 if (world > 1 or args.exchange) else 1
+    comps = [torch.empty(bound + 256, dtype=torch.uint8, device=device) for _ in range(nbuf)]  # +256: segments are padded to 256 B
+    offss = [torch.zeros(nblocks + 1, dtype=torch.int64, device=device) for _ in range(nbuf)]
     out = torch.empty(n, dtype=torch.uint8, device=device)
     concat = torch.empty((bound + 256) * world, dtype=torch.uint8, device=device) if exchange else None
     staging = torch.empty((bound + 256) * world, dtype=torch.uint8, device=device) if exchange else None
     side = torch.cuda.Stream(device=device) if exchange else None
     main_stream = torch.cuda.current_stream()
     gather_ms = []
+    released = [None] * nbuf  # event: the exchange that read buffer b has finished
+    state = {"i": 0, "table": None, "last": 0}
 
     def step():
+        b = state["i"] % nbuf
+        state["i"] += 1
+        state["last"] = b
+        comp, offs = comps[b], offss[b]
+        if released[b] is not None:
+            main_stream.wait_event(released[b])
         ctx.encode_blocks_device(src, block, comp, offs)
         if not exchange:
             # the decoder takes the block table from HBM: no host round trip inside the step
             ctx.decode_blocks_device(comp, bound, offs, n, block, out)
             return
         total = int(offs[-1])  # the exchange needs the segment size on the host
-        side.wait_stream(main_stream)
+        side.wait_stream(main_stream)  # (exchanges also queue behind each other on the side stream)
         ctx.decode_blocks_device(comp, total, offs, n, block, out)   # own shard, overlaps the exchange
         with torch.cuda.stream(side):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -167,8 +178,8 @@ def main() -> None:
                 w.wait()
             e1.record()
             gather_ms.append((e0, e1))
-            step.table = table
-        main_stream.wait_stream(side)
+            state["table"] = table
+            released[b] = e1
 
     def fence():
         torch.cuda.synchronize()
@@ -195,6 +206,7 @@ def main() -> None:
     timing = ctx.get_timing(reset=True)
     st, bad = ctx.sync_status(raise_on_error=False)
     roundtrip_ok = bool(torch.equal(out, src)) and st == 0
+    comp, offs = comps[state["last"]], offss[state["last"]]
     total = int(offs[-1])
     ratio = total / n
 
@@ -206,7 +218,7 @@ def main() -> None:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         roundtrip_ok = bool(int(ok[0]))
         # the concatenated stream must hold this rank's segment at its base
-        bases = [int(x) for x in (step.table[::nblocks][:world]).cpu()]
+        bases = [int(x) for x in (state["table"][::nblocks][:world]).cpu()]
         roundtrip_ok = roundtrip_ok and bool(torch.equal(concat[bases[rank]: bases[rank] + total], comp[:total]))
 
     if rank == 0:
@@ -238,7 +250,7 @@ def main() -> None:
                                    f"encode+decode round trip resident in HBM (BASELINE.json configs[1])",
                        "bytes_per_gpu": n, "block": block, "blocks_per_gpu": nblocks,
                        "parallelism": f"blocks sharded over {world} GPU(s), one process per GPU"
-                                      + ("; allgatherv of the compressed segments overlapped with decode" if exchange else "")},
+                                      + ("; allgatherv of the compressed segments overlapped with the decode and with the next step's encode" if exchange else "")},
             "roundtrip_ok": roundtrip_ok, "ratio": round(ratio, 6),
             "encode_MBps": round(n / 1e6 / ((enc_ms + scan_ms + scat_ms) * 1e-3), 1),
             "decode_MBps": round(n / 1e6 / (dec_ms * 1e-3), 1),
