@@ -349,7 +349,6 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
                              const uint64_t* d_offsets, uint64_t nblocks, uint32_t block,
                              uint64_t n, void* d_dst, void* stream)
 {
-    (void)comp_size;
     if (!c || !block_ok(block) || (nblocks && (!d_comp || !d_offsets || !d_dst))) return RCX_E_ARG;
     if (coder != RCX_CODER_ADAPTIVE && coder != RCX_CODER_STATIC) return RCX_E_ARG;
     if (nblocks != rcx_block_count(n, block)) return RCX_E_ARG;
@@ -368,11 +367,11 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
             const u64 per_wg = RCX_QUAD_BLOCKS * RCX_QUAD_DEC_WAVES;
             const u32 grid = (u32)((nblocks + per_wg - 1) / per_wg);
             hipLaunchKernelGGL(rcx_dec_static_quad_k<RCX_QUAD_DEC_WAVES>, dim3(grid), dim3(64 * RCX_QUAD_DEC_WAVES), 0, s,
-                               static_cast<const u8*>(d_comp), d_offsets, nblocks, block, n, static_cast<u8*>(d_dst), c->status,
+                               static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks, block, n, static_cast<u8*>(d_dst), c->status,
                                c->redo);
         } else if (coder == RCX_CODER_STATIC) {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
-            hipLaunchKernelGGL(rcx_dec_static_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
+            hipLaunchKernelGGL(rcx_dec_static_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks,
                                block, n, static_cast<u8*>(d_dst), c->status, static_cast<u32*>(nullptr),
                                static_cast<const u32*>(nullptr));
         } else if (decode_lanes(c, nblocks) == 4) {
@@ -380,11 +379,11 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
                 const u64 per_wg = RCX_QUAD_BLOCKS * RCX_QUAD_DEC_WAVES;
                 const u32 grid = (u32)((nblocks + per_wg - 1) / per_wg);
                 hipLaunchKernelGGL(rcx_dec_quad_k<RCX_QUAD_DEC_WAVES>, dim3(grid), dim3(64 * RCX_QUAD_DEC_WAVES), 0, s,
-                                   static_cast<const u8*>(d_comp), d_offsets, nblocks, block, n, static_cast<u8*>(d_dst), c->divtab,
+                                   static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks, block, n, static_cast<u8*>(d_dst), c->divtab,
                                    c->status, c->redo);
             } else {
                 const u32 grid = (u32)((nblocks + RCX_QUAD_BLOCKS - 1) / RCX_QUAD_BLOCKS);
-                hipLaunchKernelGGL(rcx_dec_quad_k<1>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
+                hipLaunchKernelGGL(rcx_dec_quad_k<1>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks,
                                    block, n, static_cast<u8*>(d_dst), c->divtab, c->status, c->redo);
             }
         } else if (decode_lanes(c, nblocks) == 8) {
@@ -392,16 +391,16 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
                 const u64 per_wg = RCX_OCT_BLOCKS * RCX_OCT_DEC_WAVES;
                 const u32 grid = (u32)((nblocks + per_wg - 1) / per_wg);
                 hipLaunchKernelGGL(rcx_dec_oct_k<RCX_OCT_DEC_WAVES>, dim3(grid), dim3(64 * RCX_OCT_DEC_WAVES), 0, s,
-                                   static_cast<const u8*>(d_comp), d_offsets, nblocks, block, n, static_cast<u8*>(d_dst), c->divtab,
+                                   static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks, block, n, static_cast<u8*>(d_dst), c->divtab,
                                    c->status);
             } else {
                 const u32 grid = (u32)((nblocks + RCX_OCT_BLOCKS - 1) / RCX_OCT_BLOCKS);
-                hipLaunchKernelGGL(rcx_dec_oct_k<1>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
+                hipLaunchKernelGGL(rcx_dec_oct_k<1>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks,
                                    block, n, static_cast<u8*>(d_dst), c->divtab, c->status);
             }
         } else {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
-            hipLaunchKernelGGL(rcx_dec_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets,
+            hipLaunchKernelGGL(rcx_dec_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets,
                                nblocks, block, n, static_cast<u8*>(d_dst), c->divtab, c->status, static_cast<u32*>(nullptr),
                                static_cast<const u32*>(nullptr));
         }
@@ -411,13 +410,13 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
         // the quad kernel: the one-lane kernel, which has the reference's fall-through for that case, decodes
         // them again.  On valid input nothing is marked and every wave of this launch returns at once.
         const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
-        hipLaunchKernelGGL(rcx_dec_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets,
+        hipLaunchKernelGGL(rcx_dec_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets,
                            nblocks, block, n, static_cast<u8*>(d_dst), c->divtab, c->status, static_cast<u32*>(nullptr),
                            static_cast<const u32*>(c->redo));
     }
     if (squad) { // the same for the static coder: a target past the table or a symbol of count 0
         const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
-        hipLaunchKernelGGL(rcx_dec_static_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), d_offsets, nblocks,
+        hipLaunchKernelGGL(rcx_dec_static_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks,
                            block, n, static_cast<u8*>(d_dst), c->status, static_cast<u32*>(nullptr), static_cast<const u32*>(c->redo));
     }
     return hipGetLastError() == hipSuccess ? RCX_OK : RCX_E_HIP;
@@ -581,7 +580,7 @@ int rcx_stream_decode(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
         const u64 offs[2] = {0, comp_size};
         HIP_TRY(hipMemcpy(c->h_in, comp, comp_size, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->h_off, offs, sizeof(offs), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(rcx_dec_static_k<true>, dim3(1), dim3(64), 0, nullptr, c->h_in, c->h_off, (u64)1, block, count, c->h_out,
+        hipLaunchKernelGGL(rcx_dec_static_k<true>, dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)comp_size, c->h_off, (u64)1, block, count, c->h_out,
                            c->status, c->status + 2, static_cast<const u32*>(nullptr));
         if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
         HIP_TRY(hipMemcpy(c->status_host, c->status, 4 * sizeof(u32), hipMemcpyDeviceToHost));
@@ -618,7 +617,7 @@ int rcx_stream_decode(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
     const u64 offs[2] = {0, comp_size};
     HIP_TRY(hipMemcpy(c->h_in, comp, comp_size, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->h_off, offs, sizeof(offs), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(rcx_dec_adaptive_k<true>, dim3(1), dim3(64), 0, nullptr, c->h_in, c->h_off, (u64)1, block, count, c->h_out,
+    hipLaunchKernelGGL(rcx_dec_adaptive_k<true>, dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)comp_size, c->h_off, (u64)1, block, count, c->h_out,
                        c->divtab, c->status, c->status + 2, static_cast<const u32*>(nullptr));
     if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
     HIP_TRY(hipMemcpy(c->status_host, c->status, 4 * sizeof(u32), hipMemcpyDeviceToHost));

@@ -209,7 +209,7 @@ static __device__ unsigned long long rcx_dec_stamp_out[8];
 // the header (max(declared,1) clipped to the sink); track[0] = first symbol whose normalize
 // ran out of input, or 0xFFFFFFFF.
 template <bool STREAM>
-__global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ comp, const u64* __restrict__ offsets, u64 nblocks,
+__global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ comp, u64 comp_size, const u64* __restrict__ offsets, u64 nblocks,
                                                          u32 block, u64 n, u8* __restrict__ dst,
                                                          const DivEntry* __restrict__ divtab, u32* status, u32* track,
                                                          const u32* __restrict__ only)
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ 
     if (live) {
         const u64 s0 = offsets[blk], s1 = offsets[blk + 1];
         stream_len = s1 - s0;
-        if (s1 < s0 || stream_len < (STREAM ? 8u : 9u)) { // cpprcoder.h:878: fewer than 8 bytes cannot even start
+        if (s1 < s0 || s1 > comp_size || stream_len < (STREAM ? 8u : 9u)) { // cpprcoder.h:878: fewer than 8 bytes cannot even start
             rcx_flag(status, RCX_ST_CORRUPT, blk);
             live = false;
             len = 0;

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64) void rcx_enc_oct_k(const u8* __restrict__ src, 
 // kernel time); with many blocks single-wave workgroups pack more waves onto a CU.
 #define RCX_OCT_DEC_WAVES 8
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void rcx_dec_oct_k(const u8* __restrict__ comp, const u64* __restrict__ offsets,
+__global__ __launch_bounds__(64 * WAVES) void rcx_dec_oct_k(const u8* __restrict__ comp, u64 comp_size, const u64* __restrict__ offsets,
                                                             u64 nblocks, u32 block, u64 n, u8* __restrict__ dst,
                                                             const DivEntry* __restrict__ divtab, u32* status)
 {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_oct_k(const u8* __restrict
     if (live) {
         const u64 s0 = offsets[blk], s1 = offsets[blk + 1];
         stream_len = s1 - s0;
-        if (s1 < s0 || stream_len < 9) {
+        if (s1 < s0 || s1 > comp_size || stream_len < 9) {
             if (j == 0) rcx_flag(status, RCX_ST_CORRUPT, blk);
             live = false;
             len = 0;
@@ -741,7 +741,7 @@ struct QuadInput {
 // CU (single-wave workgroups do not: measured 25.4 -> 19.3 ms per GiB at 16384 blocks).
 #define RCX_QUAD_DEC_WAVES 4
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restrict__ comp, const u64* __restrict__ offsets,
+__global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restrict__ comp, u64 comp_size, const u64* __restrict__ offsets,
                                                              u64 nblocks, u32 block, u64 n, u8* __restrict__ dst,
                                                              const DivEntry* __restrict__ divtab, u32* status,
                                                              u32* __restrict__ redo)
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
     if (live) {
         const u64 s0 = offsets[blk], s1 = offsets[blk + 1];
         stream_len = s1 - s0;
-        if (s1 < s0 || stream_len < 9) {
+        if (s1 < s0 || s1 > comp_size || stream_len < 9) {
             if (j == 0) rcx_flag(status, RCX_ST_CORRUPT, blk);
             live = false;
             len = 0;

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(RCX_ST3_THREADS) void rcx_enc_static3_k(const u8* _
 // STREAM = the single-stream entry point: one block whose symbol count n the host took from the header;
 // track[0] = first symbol whose renormalisation ran out of input (cpprcoder.h:506-509), or 0xFFFFFFFF.
 template <bool STREAM>
-__global__ __launch_bounds__(64) void rcx_dec_static_k(const u8* __restrict__ comp, const u64* __restrict__ offsets, u64 nblocks,
+__global__ __launch_bounds__(64) void rcx_dec_static_k(const u8* __restrict__ comp, u64 comp_size, const u64* __restrict__ offsets, u64 nblocks,
                                                        u32 block, u64 n, u8* __restrict__ dst, u32* status, u32* track,
                                                        const u32* __restrict__ only)
 {
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(64) void rcx_dec_static_k(const u8* __restrict__ co
         stream_len = s1 - s0;
         const u8* s = comp + s0;
         // cpprcoder.h:474-493: at least the header, one more byte, then 5 bytes for the lead-in and low
-        bool good = s1 >= s0 && stream_len >= RCX_STATIC_HEADER + 5;
+        bool good = s1 >= s0 && s1 <= comp_size && stream_len >= RCX_STATIC_HEADER + 5; // (an offset table that points past the buffer is not followed)
         if (good) {
             const u32 declared = (u32)s[0] | ((u32)s[1] << 8) | ((u32)s[2] << 16) | ((u32)s[3] << 24);
             good = STREAM || declared == len;
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(64) void rcx_dec_static_k(const u8* __restrict__ co
 // ===========================================================================
 #define RCX_SQUAD_LDS_BYTES (4 * RCX_QUAD_GROUP_BYTES + RCX_QUAD_BLOCKS * RCX_QUAD_RING_BYTES)
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void rcx_dec_static_quad_k(const u8* __restrict__ comp, const u64* __restrict__ offsets,
+__global__ __launch_bounds__(64 * WAVES) void rcx_dec_static_quad_k(const u8* __restrict__ comp, u64 comp_size, const u64* __restrict__ offsets,
                                                                     u64 nblocks, u32 block, u64 n, u8* __restrict__ dst,
                                                                     u32* status, u32* __restrict__ redo)
 {
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_static_quad_k(const u8* __
         stream_len = s1 - s0;
         const u8* s = comp + s0;
         // cpprcoder.h:474-493: at least the header, one more byte, then 5 bytes for the lead-in and low
-        bool good = s1 >= s0 && stream_len >= RCX_STATIC_HEADER + 5;
+        bool good = s1 >= s0 && s1 <= comp_size && stream_len >= RCX_STATIC_HEADER + 5; // (an offset table that points past the buffer is not followed)
         if (good) {
             const u32 declared = (u32)s[0] | ((u32)s[1] << 8) | ((u32)s[2] << 16) | ((u32)s[3] << 24);
             good = declared == len;

@@ -103,7 +103,8 @@ int rcx_encode_blocks_device(rcx_ctx* ctx, int coder, const void* d_src, uint64_
  * Decode blocks produced by rcx_encode_blocks_device (or by the reference, block by block).
  * Replaces, per block: AdaptiveRangeDecoder<T>::initialize + decode (cpprcoder.h:859-924)
  * or RangeEncoder<T>::decode (cpprcoder.h:460-519).
- *   d_comp     the compacted streams, comp_size bytes
+ *   d_comp     the compacted streams, comp_size bytes (a block whose offsets point past comp_size is reported
+ *              as RCX_E_CORRUPT and not read)
  *   d_offsets  nblocks+1 u64 as written by the encoder
  *   n          total decoded size; block b must declare min(block, n - b*block) bytes
  *   d_dst      n output bytes

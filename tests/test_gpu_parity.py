@@ -161,6 +161,11 @@ def test_errors_are_reported_not_fatal(ctx, oracle):
     cut[-1] -= 40
     _, st, blk = gpu_decode(ctx, payload[: int(cut[-1])], cut, len(data), 65536)
     assert st == rcx.E_CORRUPT and blk == 4
+    # an offset table that points past the compressed buffer is not followed
+    _, st, blk = gpu_decode(ctx, payload[:-100], offsets, len(data), 65536)
+    assert st == rcx.E_CORRUPT and blk == 4
+    _, st, blk = gpu_decode(ctx, payload[:-100], offsets, len(data), 65536, coder=0, comp_offset=3)
+    assert st == rcx.E_CORRUPT and blk == 4
     # the context is still usable afterwards
     back, st, _ = gpu_decode(ctx, payload, offsets, len(data), 65536)
     assert st == 0 and np.array_equal(back, data)
