@@ -274,6 +274,28 @@ def test_static_carry_through_long_runs_of_ff(ctx, oracle):
     assert st == 0 and np.array_equal(back, data) and ctx.last_redo(len(runs)) == 0
 
 
+def test_bursts_of_very_improbable_symbols(ctx, oracle):
+    """After ~2^20 equal bytes every other byte value costs 20 bits: 2.5 output bytes per symbol for a while.
+    That is more than the decoder's fast input top-up supplies (8 dwords per 16 symbols: its synchronous refill
+    runs) and more than one 16-byte piece per chunk for the encoder's drain."""
+    block = 1 << 20
+    def one(fill, seed):
+        rs = np.random.RandomState(seed)
+        d = np.full(block, fill, np.uint8)
+        others = np.array([v for v in range(256) if v != fill], np.uint8)
+        tail = np.concatenate([rs.permutation(others) for _ in range(24)])
+        d[block - len(tail):] = tail
+        d[5000:5000 + 255] = rs.permutation(others)  # and once early, at 13 bits per symbol
+        return d
+    data = np.concatenate([one(65, 1), one(0, 2), one(255, 3), workloads.zipf(block, 4)])
+    payload, offsets, _ = gpu_encode(ctx, data, block)
+    slots, sizes = oracle.encode_blocks(data, block, threads=4)
+    assert_same_blocks(payload, offsets, slots, sizes)
+    back, st, _ = gpu_decode(ctx, payload, offsets, len(data), block)
+    assert st == 0 and np.array_equal(back, data)
+    assert ctx.last_redo(4) == 0
+
+
 def test_single_stream_semantics(ctx, oracle, golden):
     """rcx_stream_encode / rcx_stream_decode == the reference's initialize+encode / initialize+decode
     on a MemoryStream of the given capacity (cpprcoder.h:678-720, 859-924, 1047-1054)."""
