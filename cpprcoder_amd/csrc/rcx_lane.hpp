@@ -269,7 +269,7 @@ struct EncLane {
     // One symbol with the model's answer already in hand: cum = sum of the counts below the
     // symbol, f = its count (cpprcoder.h:703-711).  Two halves so that they can also run in two
     // different waves: arith() is the interval arithmetic (state: low, range) and returns a
-    // record {top 24 bits of the moved low | bytes leaving << 1 | carry}; emit() is the byte
+    // record {top 24 bits of the moved low | 8 x the bytes leaving, in bits 3..4 | carry}; emit() is the byte
     // writer (state: acc, nacc8, pos).
     // WIDE: full 32-bit multiplies (the static coder's total can be tiny, so t can exceed 24 bits).
     template <bool WIDE = false>
@@ -282,7 +282,7 @@ struct EncLane {
         const u32 k8 = rcx_clz(range) & 0x18u;       // :783-800: k8/8 bytes leave through the top of low
         low = moved << k8;
         range <<= k8;
-        return (moved & 0xFFFFFF00u) | (k8 >> 2) | carry;
+        return (moved & 0xFFFFFF00u) | k8 | carry; // k8 is 0, 8, 16 or 24: bits 3 and 4
     }
     // the same with the divisor's fields passed separately (the addend as the 64-bit pair the multiply-add takes)
     RCX_DEV u32 arith_q(u32 cum, u32 f, u32 mul, u32 shift, u64 add)
@@ -294,11 +294,11 @@ struct EncLane {
         const u32 k8 = rcx_clz(range) & 0x18u;
         low = moved << k8;
         range <<= k8;
-        return (moved & 0xFFFFFF00u) | (k8 >> 2) | carry;
+        return (moved & 0xFFFFFF00u) | k8 | carry; // k8 is 0, 8, 16 or 24: bits 3 and 4
     }
     RCX_DEV void emit(u32 rec)
     {
-        const u32 k8 = (rec << 2) & 0x18u;
+        const u32 k8 = rec & 0x18u;
         acc += rec & 1u;                             // :767-781 carry, resolved lazily (see flush)
         acc = (acc << k8) | (((u64)rec << k8) >> 32);
         nacc8 += k8;
@@ -308,7 +308,7 @@ struct EncLane {
     RCX_DEV void code(u32 cum, u32 f, const DivEntry& k, u32 index = 0)
     {
         const u32 rec = arith<WIDE>(cum, f, k);
-        if (TRACK) track(index, rec & 1u, rec & 0xFFFFFF00u, (rec << 2) & 0x18u);
+        if (TRACK) track(index, rec & 1u, rec & 0xFFFFFF00u, rec & 0x18u);
         emit(rec);
     }
 

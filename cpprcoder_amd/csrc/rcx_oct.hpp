@@ -1122,7 +1122,7 @@ struct StagedWriter {
     }
     __device__ __forceinline__ void emit(u32 rec)
     {
-        const u32 k8 = (rec << 2) & 0x18u;
+        const u32 k8 = rec & 0x18u;
         acc += rec & 1u;                                     // cpprcoder.h:767-781, resolved lazily
         acc = (acc << k8) | (((u64)rec << k8) >> 32);
         nacc8 += k8;
