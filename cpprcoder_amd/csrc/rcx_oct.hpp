@@ -643,11 +643,14 @@ __device__ __forceinline__ u32 rcx_quad_excl_scan(u32 x, u32 m1, u32 m2)
 // store the same values).
 // Ring: dword d of the stream (counted from `origin`, the 16-byte aligned address at or below the
 // first payload byte) lives in ring[d % 32]; ring[32] repeats ring[0] so that the pair (d, d+1)
-// is always one ds_read2_b32.  Every 16 symbols (which consume at most 12 dwords) topup() moves
-// the two 16-byte pieces it requested the time before into the ring and requests the next two --
-// unconditionally: a piece the ring has no room for is written to the scratch area instead and
-// asked for again.  A quad that falls behind (more than 8 dwords per 16 symbols: possible, rare)
-// is refilled synchronously on a cold branch.
+// is always one ds_read2_b32.  Every 16 symbols (which consume at most 12 dwords) topup() moves the 16-byte
+// piece it requested the time before into the ring and requests the next one -- unconditionally: a piece the
+// ring has no room for is written to the scratch area instead and asked for again.  One piece per 16 symbols is
+// one byte per symbol: a quad that needs more (expanding data for a while, or a burst of improbable symbols)
+// falls behind and is refilled synchronously, up to 24 dwords ahead, on a cold branch.
+#if !defined(RCX_TOPUP_PIECES)
+#define RCX_TOPUP_PIECES 1 /* 16-byte pieces requested per top-up on the fast path (2: 1 % slower on 1.0-ratio data) */
+#endif
 struct QuadInput {
     u32 low, range;
     u32 bp8;        // bits of the stream consumed, counted from `origin`
@@ -722,16 +725,20 @@ struct QuadInput {
     __device__ __forceinline__ void topup()
     {
         ring_put(pendA, nfit >= 1);
+#if RCX_TOPUP_PIECES > 1
         ring_put(pendB, nfit >= 2);
+#endif
         const u32 rd = bp8 >> 5; // ring[rd % 32 ...] are unread
         if (rcx_any(wr - rd < 14u)) { // the next 16 symbols may need 12 dwords and the pair after them
             asm volatile("" ::: "memory"); // keep this a branch: taken only on a run of very improbable symbols
             while (__any(wr - rd <= 20u)) ring_put(load16(4 * wr), wr - rd <= 20u);
         }
         const u32 room = (rd + RCX_RING_DW - wr) >> 2;
-        nfit = room < 2u ? room : 2u;
+        nfit = room < (u32)RCX_TOPUP_PIECES ? room : (u32)RCX_TOPUP_PIECES;
         pendA = load16(4 * wr);
+#if RCX_TOPUP_PIECES > 1
         pendB = load16(4 * wr + 16);
+#endif
     }
     // stream bytes consumed so far, header included (cpprcoder.h:901-903)
     __device__ __forceinline__ u64 taken() const { return 8 + (u64)((bp8 - body8) >> 3); }
