@@ -50,7 +50,7 @@ def parse(blob):
         raise ContainerError("not an RCXB container")
     if version != VERSION or coder not in (0, 1) or reserved != 0:
         raise ContainerError("unsupported container version or coder")
-    if block < 16 or block > (1 << 20) or nblocks != (n + block - 1) // block:
+    if block < 16 or block > (1 << 24) - 256 or nblocks != (n + block - 1) // block:
         raise ContainerError("inconsistent header")
     end = _FIXED.size + 8 * (nblocks + 1)
     if len(buf) < end:

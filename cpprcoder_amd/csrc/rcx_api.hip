@@ -36,6 +36,9 @@ struct rcx_ctx {
     int lanes_per_block = 0; // decode: 0 = default (4, the quad kernel), 8 = octet, 4 = quad, 1 = one lane per block (RCX_LANES_PER_BLOCK)
     int wide_wg = -1;        // decode workgroups: -1/1 = multi-wave (default), 0 = single-wave (RCX_WIDE_WG)
     int enc_variant = 3;     // encode: 0 = one wave per 64 blocks, 1 = octet, 2 = 4-wave model/coder split, 3 = 5-wave split (RCX_ENC_VARIANT)
+    int enc_lanes = 0;       // blocks per multi-wave encode workgroup: 0 = from the block count, else 1..64 (RCX_ENC_LANES)
+    int dec_quads = 0;       // blocks per quad-decoder wave: 0 = from the block count, else 1, 2, 4, 8, 16 (RCX_DEC_QUADS)
+    int cus = 256;           // compute units of the device
     // scratch
     u8* slots = nullptr;
     u64 slots_bytes = 0;
@@ -102,6 +105,13 @@ int grow(void** p, u64* have, u64 want)
     return RCX_OK;
 }
 
+// Entry i serves total = 256 + i (rcx_divtab.hpp); built on the device, 16 bytes per symbol of the largest block.
+__global__ void rcx_divtab_k(DivEntry* __restrict__ tab, u64 entries)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < entries) tab[i] = rcx_make_div_entry((u32)(256 + i));
+}
+
 int ensure_divtab(rcx_ctx* c, u32 block)
 {
     if (c->divtab && c->divtab_block >= block) return RCX_OK;
@@ -109,13 +119,12 @@ int ensure_divtab(rcx_ctx* c, u32 block)
     u32 cover = 1u << 16;
     while (cover < block) cover <<= 1;
     const u64 entries = (u64)cover + 2 * RCX_STAGE;
-    std::vector<DivEntry> host(entries);
-    for (u64 i = 0; i < entries; ++i) host[i] = rcx_make_div_entry((u32)(256 + i));
     if (c->divtab) (void)hipFree(c->divtab);
     c->divtab = nullptr;
     c->divtab_block = 0;
     if (hipMalloc(reinterpret_cast<void**>(&c->divtab), entries * sizeof(DivEntry)) != hipSuccess) return RCX_E_NOMEM;
-    if (hipMemcpy(c->divtab, host.data(), entries * sizeof(DivEntry), hipMemcpyHostToDevice) != hipSuccess) return RCX_E_HIP;
+    hipLaunchKernelGGL(rcx_divtab_k, dim3((u32)((entries + 255) / 256)), dim3(256), 0, nullptr, c->divtab, entries);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return RCX_E_HIP;
     c->divtab_block = cover;
     return RCX_OK;
 }
@@ -138,6 +147,30 @@ int decode_lanes(const rcx_ctx* c, u64 nblocks)
 {
     (void)nblocks;
     return c->lanes_per_block ? c->lanes_per_block : 4;
+}
+
+// Launch shape.  A wave-instruction costs its SIMD the same whatever its lanes do, and a block is one serial
+// chain, so with few blocks the work is spread thin rather than packed: the multi-wave encoders carry
+// `lanes` blocks per workgroup such that every CU has a workgroup before any carries 64, the quad decoders
+// `quads` blocks per wave such that every SIMD has a wave before any carries 16.
+u32 pow2_at_least(u64 x)
+{
+    u32 p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+u32 encode_lanes(const rcx_ctx* c, u64 nblocks)
+{
+    if (c->enc_lanes) return (u32)c->enc_lanes;
+    const u32 want = pow2_at_least((nblocks + c->cus - 1) / c->cus);
+    return want > RCX_LANES ? RCX_LANES : want;
+}
+u32 decode_quads(const rcx_ctx* c, u64 nblocks)
+{
+    if (c->dec_quads) return (u32)c->dec_quads;
+    const u64 simds = 4ull * c->cus;
+    const u32 want = pow2_at_least((nblocks + simds - 1) / simds);
+    return want > RCX_QUAD_BLOCKS ? RCX_QUAD_BLOCKS : want;
 }
 
 int ensure_redo(rcx_ctx* c, u64 nblocks)
@@ -186,12 +219,14 @@ const char* rcx_status_string(int status)
 
 uint64_t rcx_block_count(uint64_t n, uint32_t block) { return block ? (n + block - 1) / block : 0; }
 
-// Worst case of one adaptive block: n + (255/2)*log2(n)/8 (estimator regret) + the
-// truncation loss of t = range/total, < n/64 for block <= 2^20; plus the 9 framing bytes.
+// Worst case of one adaptive block: n + (255/2)*log2(n)/8 (estimator regret) + the truncation loss of
+// t = range/total, which is < log2(1 + 1/t) bits per symbol: < n/64 bytes while total <= 2^20 (t >= 16), and up to
+// one bit per symbol as the total approaches 2^24 (t >= 1); plus the 9 framing bytes.
 // The static coder needs 521 + n + slack.  Rounded to 16 so slots keep 16-byte alignment.
 uint64_t rcx_block_bound(uint32_t block)
 {
     uint64_t b = (uint64_t)block + block / 32 + 1024;
+    if (block > (1u << 20)) b += block / 8;
     return (b + 15) & ~(uint64_t)15;
 }
 
@@ -211,6 +246,12 @@ int rcx_ctx_create(int device, rcx_ctx** out)
     if (const char* v = getenv("RCX_LANES_PER_BLOCK")) c->lanes_per_block = (atoi(v) == 1 || atoi(v) == 4 || atoi(v) == 8) ? atoi(v) : 0;
     if (const char* v = getenv("RCX_WIDE_WG")) c->wide_wg = atoi(v) ? 1 : 0;
     if (const char* v = getenv("RCX_ENC_VARIANT")) c->enc_variant = atoi(v) >= 0 && atoi(v) <= 3 ? atoi(v) : 3;
+    if (const char* v = getenv("RCX_ENC_LANES")) c->enc_lanes = atoi(v) >= 1 && atoi(v) <= 64 ? atoi(v) : 0;
+    if (const char* v = getenv("RCX_DEC_QUADS")) { const int q = atoi(v); c->dec_quads = (q == 1 || q == 2 || q == 4 || q == 8 || q == 16) ? q : 0; }
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cus = cus;
+    }
     if (hipMalloc(reinterpret_cast<void**>(&c->status), 4 * sizeof(u32)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&c->status_host), 4 * sizeof(u32), hipHostMallocDefault) != hipSuccess) {
         rcx_ctx_destroy(c);
@@ -293,17 +334,19 @@ int rcx_encode_blocks_device(rcx_ctx* c, int coder, const void* d_src, uint64_t 
     {
         Timed t(c, s, RCX_T_ENCODE);
         if (static3) {
-            const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
+            const u32 lanes = encode_lanes(c, nblocks);
+            const u32 grid = (u32)((nblocks + lanes - 1) / lanes);
             hipLaunchKernelGGL(rcx_enc_static3_k, dim3(grid), dim3(RCX_ST3_THREADS), 0, s, static_cast<const u8*>(d_src), n, block,
-                               nblocks, c->slots, slot, c->sizes, c->status, c->redo);
+                               nblocks, c->slots, slot, c->sizes, c->status, c->redo, lanes);
         } else if (coder == RCX_CODER_STATIC) {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_enc_static_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block, nblocks,
                                c->slots, slot, c->sizes, c->status, static_cast<const u32*>(nullptr));
         } else if (c->enc_variant == 3) {
-            const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
+            const u32 lanes = encode_lanes(c, nblocks);
+            const u32 grid = (u32)((nblocks + lanes - 1) / lanes);
             hipLaunchKernelGGL(rcx_enc_mc5_k, dim3(grid), dim3(RCX_MC5_THREADS), 0, s, static_cast<const u8*>(d_src), n, block,
-                               nblocks, c->slots, slot, c->sizes, c->divtab, c->status, c->redo);
+                               nblocks, c->slots, slot, c->sizes, c->divtab, c->status, c->redo, lanes);
         } else if (c->enc_variant == 2) {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_enc_mc_k, dim3(grid), dim3(RCX_MC_THREADS), 0, s, static_cast<const u8*>(d_src), n, block, nblocks,
@@ -364,27 +407,29 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
     {
         Timed t(c, s, RCX_T_DECODE);
         if (coder == RCX_CODER_STATIC && decode_lanes(c, nblocks) != 1) {
-            const u64 per_wg = RCX_QUAD_BLOCKS * RCX_QUAD_DEC_WAVES;
+            const u32 quads = decode_quads(c, nblocks);
+            const u64 per_wg = (u64)quads * RCX_QUAD_DEC_WAVES;
             const u32 grid = (u32)((nblocks + per_wg - 1) / per_wg);
             hipLaunchKernelGGL(rcx_dec_static_quad_k<RCX_QUAD_DEC_WAVES>, dim3(grid), dim3(64 * RCX_QUAD_DEC_WAVES), 0, s,
                                static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks, block, n, static_cast<u8*>(d_dst), c->status,
-                               c->redo);
+                               c->redo, quads);
         } else if (coder == RCX_CODER_STATIC) {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_dec_static_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks,
                                block, n, static_cast<u8*>(d_dst), c->status, static_cast<u32*>(nullptr),
                                static_cast<const u32*>(nullptr));
         } else if (decode_lanes(c, nblocks) == 4) {
+            const u32 quads = decode_quads(c, nblocks);
             if (wide_workgroups(c, nblocks)) {
-                const u64 per_wg = RCX_QUAD_BLOCKS * RCX_QUAD_DEC_WAVES;
+                const u64 per_wg = (u64)quads * RCX_QUAD_DEC_WAVES;
                 const u32 grid = (u32)((nblocks + per_wg - 1) / per_wg);
                 hipLaunchKernelGGL(rcx_dec_quad_k<RCX_QUAD_DEC_WAVES>, dim3(grid), dim3(64 * RCX_QUAD_DEC_WAVES), 0, s,
                                    static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks, block, n, static_cast<u8*>(d_dst), c->divtab,
-                                   c->status, c->redo);
+                                   c->status, c->redo, quads);
             } else {
-                const u32 grid = (u32)((nblocks + RCX_QUAD_BLOCKS - 1) / RCX_QUAD_BLOCKS);
+                const u32 grid = (u32)((nblocks + quads - 1) / quads);
                 hipLaunchKernelGGL(rcx_dec_quad_k<1>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks,
-                                   block, n, static_cast<u8*>(d_dst), c->divtab, c->status, c->redo);
+                                   block, n, static_cast<u8*>(d_dst), c->divtab, c->status, c->redo, quads);
             }
         } else if (decode_lanes(c, nblocks) == 8) {
             if (wide_workgroups(c, nblocks)) {
@@ -493,20 +538,27 @@ int rcx_decode_blocks(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
 // ---------------------------------------------------------------------------
 
 int rcx_stream_encode(rcx_ctx* c, int coder, const uint8_t* src, uint32_t n,
-                      uint8_t* dst, uint64_t sink_capacity, uint64_t* dst_size, uint32_t* request_size)
+                      uint8_t* dst, uint64_t dst_cap, uint64_t sink_capacity, uint64_t* dst_size, uint32_t* request_size)
 {
     if (!c || !dst || !dst_size || (n && !src)) return RCX_E_ARG;
-    if ((coder != RCX_CODER_ADAPTIVE && coder != RCX_CODER_STATIC) || n > RCX_MAX_BLOCK) return RCX_E_ARG;
+    if ((coder != RCX_CODER_ADAPTIVE && coder != RCX_CODER_STATIC) || n > RCX_MAX_STREAM) return RCX_E_ARG;
     HIP_TRY(hipSetDevice(c->device));
     *dst_size = 0;
     if (request_size) *request_size = 0;
     const u32 block = n < RCX_MIN_BLOCK ? RCX_MIN_BLOCK : n;
-    int r = reserve(c, block, block);
+    const bool longer = n > RCX_MAX_BLOCK; // past the table halving of cpprcoder.h:1138: the lane divides by its own total
+    const u64 slot = rcx_block_bound(block);
+    int r = longer ? RCX_OK : ensure_divtab(c, block);
     if (r != RCX_OK) return r;
+    r = grow(reinterpret_cast<void**>(&c->slots), &c->slots_bytes, slot + 256);
+    if (r != RCX_OK) return r;
+    u64 sizes_bytes = c->sizes_count * sizeof(u32);
+    r = grow(reinterpret_cast<void**>(&c->sizes), &sizes_bytes, 2 * sizeof(u32));
+    if (r != RCX_OK) return r;
+    c->sizes_count = sizes_bytes / sizeof(u32);
     r = grow(reinterpret_cast<void**>(&c->h_in), &c->h_in_bytes, (u64)n + 64);
     if (r != RCX_OK) return r;
     if (n) HIP_TRY(hipMemcpy(c->h_in, src, n, hipMemcpyHostToDevice));
-    const u64 slot = rcx_block_bound(block);
     if (coder == RCX_CODER_STATIC) {
         // RangeEncoder<T>::encode (cpprcoder.h:375-458) returns a bool; the caller (the facade) replays the
         // sink calls itself, so the whole stream is handed back: RCX_OK, or RCX_E_CAPACITY if dst is too small.
@@ -518,12 +570,16 @@ int rcx_stream_encode(rcx_ctx* c, int coder, const uint8_t* src, uint32_t n,
         u32 ssize = 0;
         HIP_TRY(hipMemcpy(&ssize, c->sizes, sizeof(u32), hipMemcpyDeviceToHost));
         *dst_size = ssize;
-        if (ssize > sink_capacity) return RCX_E_CAPACITY;
+        if (ssize > sink_capacity || ssize > dst_cap) return RCX_E_CAPACITY;
         HIP_TRY(hipMemcpy(dst, c->slots, ssize, hipMemcpyDeviceToHost));
         return RCX_OK;
     }
-    hipLaunchKernelGGL(rcx_enc_adaptive_k<false>, dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)n, block, (u64)1, c->slots, slot,
-                       c->sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr), static_cast<const u32*>(nullptr));
+    if (longer)
+        hipLaunchKernelGGL((rcx_enc_adaptive_k<false, true>), dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)n, block, (u64)1, c->slots, slot,
+                           c->sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr), static_cast<const u32*>(nullptr));
+    else
+        hipLaunchKernelGGL((rcx_enc_adaptive_k<false, false>), dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)n, block, (u64)1, c->slots, slot,
+                           c->sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr), static_cast<const u32*>(nullptr));
     if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
     r = rcx_ctx_sync_status(c, nullptr, nullptr);
     if (r != RCX_OK) return r;
@@ -531,18 +587,24 @@ int rcx_stream_encode(rcx_ctx* c, int coder, const uint8_t* src, uint32_t n,
     HIP_TRY(hipMemcpy(&size, c->sizes, sizeof(u32), hipMemcpyDeviceToHost));
     const u64 cap16 = sink_capacity < 4 ? 4 : sink_capacity; // the header went through the growing write()
     if ((u64)size - 4 <= cap16) { // every writeByte fits; the final write(4) grows the sink (cpprcoder.h:1031-1045)
-        HIP_TRY(hipMemcpy(dst, c->slots, size, hipMemcpyDeviceToHost));
         *dst_size = size;
+        if (size > dst_cap) return RCX_E_CAPACITY;
+        HIP_TRY(hipMemcpy(dst, c->slots, size, hipMemcpyDeviceToHost));
         return RCX_OK;
     }
     // The sink fills.  Second pass: replay the reference's delayed writer to find the symbol.
-    hipLaunchKernelGGL(rcx_enc_adaptive_k<true>, dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)n, block, (u64)1, c->slots, slot,
-                       c->sizes, c->divtab, c->status, (u32)(cap16 - 4), c->status + 2, static_cast<const u32*>(nullptr));
+    *dst_size = cap16;
+    if (cap16 > dst_cap) return RCX_E_CAPACITY;
+    if (longer)
+        hipLaunchKernelGGL((rcx_enc_adaptive_k<true, true>), dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)n, block, (u64)1, c->slots, slot,
+                           c->sizes, c->divtab, c->status, (u32)(cap16 - 4), c->status + 2, static_cast<const u32*>(nullptr));
+    else
+        hipLaunchKernelGGL((rcx_enc_adaptive_k<true, false>), dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)n, block, (u64)1, c->slots, slot,
+                           c->sizes, c->divtab, c->status, (u32)(cap16 - 4), c->status + 2, static_cast<const u32*>(nullptr));
     if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
     HIP_TRY(hipMemcpy(c->status_host, c->status, 4 * sizeof(u32), hipMemcpyDeviceToHost));
     const u32 fail_at = c->status_host[2];
     HIP_TRY(hipMemcpy(dst, c->slots, cap16, hipMemcpyDeviceToHost)); // what was written before the sink filled
-    *dst_size = cap16;
     if (fail_at != 0xFFFFFFFFu) { // cpprcoder.h:708-711
         if (request_size) *request_size = n - fail_at;
         return RCX_PENDING;
@@ -554,7 +616,7 @@ int rcx_stream_decode(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
                       uint8_t* dst, uint64_t sink_capacity, uint64_t* dst_size, uint32_t* request_size)
 {
     if (!c || !dst || !dst_size || (comp_size && !comp)) return RCX_E_ARG;
-    if ((coder != RCX_CODER_ADAPTIVE && coder != RCX_CODER_STATIC) || comp_size > 0x7FFFFFFFull) return RCX_E_ARG;
+    if ((coder != RCX_CODER_ADAPTIVE && coder != RCX_CODER_STATIC) || comp_size > 0xFFFFFFFFull) return RCX_E_ARG;
     HIP_TRY(hipSetDevice(c->device));
     *dst_size = 0;
     if (request_size) *request_size = 0;
@@ -566,7 +628,7 @@ int rcx_stream_decode(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
         if (declared == 0) return RCX_OK;                            // :481-483
         if (comp_size < 516 + 1 || comp_size - 516 < 5) return RCX_ERROR; // :486-493
         const u64 count = declared < sink_capacity ? declared : sink_capacity;
-        if (count > RCX_MAX_BLOCK) return RCX_E_ARG;
+        if (count > RCX_MAX_STREAM) return RCX_E_ARG;
         if (count == 0) return RCX_OK; // nothing fits: the caller's first writeByte fails
         const u32 block = count < RCX_MIN_BLOCK ? RCX_MIN_BLOCK : (u32)count;
         int r = grow(reinterpret_cast<void**>(&c->h_in), &c->h_in_bytes, comp_size + 64);
@@ -598,13 +660,14 @@ int rcx_stream_decode(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
     const u64 cap16 = sink_capacity;
     const u64 want = declared ? declared : 1; // cpprcoder.h:912: the size test comes after the first writeByte
     const u64 count = want < cap16 ? want : cap16;
-    if (count > RCX_MAX_BLOCK) return RCX_E_ARG;
+    if (count > RCX_MAX_STREAM) return RCX_E_ARG;
     if (count == 0) { // a sink that accepts nothing: the first writeByte fails (cpprcoder.h:909-911)
         if (request_size) *request_size = declared;
         return RCX_PENDING;
     }
     const u32 block = count < RCX_MIN_BLOCK ? RCX_MIN_BLOCK : (u32)count;
-    int r = ensure_divtab(c, block);
+    const bool longer = count > RCX_MAX_BLOCK;
+    int r = longer ? RCX_OK : ensure_divtab(c, block);
     if (r != RCX_OK) return r;
     r = grow(reinterpret_cast<void**>(&c->h_in), &c->h_in_bytes, comp_size + 64);
     if (r != RCX_OK) return r;
@@ -617,8 +680,12 @@ int rcx_stream_decode(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
     const u64 offs[2] = {0, comp_size};
     HIP_TRY(hipMemcpy(c->h_in, comp, comp_size, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->h_off, offs, sizeof(offs), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(rcx_dec_adaptive_k<true>, dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)comp_size, c->h_off, (u64)1, block, count, c->h_out,
-                       c->divtab, c->status, c->status + 2, static_cast<const u32*>(nullptr));
+    if (longer)
+        hipLaunchKernelGGL((rcx_dec_adaptive_k<true, true>), dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)comp_size, c->h_off, (u64)1, block, count, c->h_out,
+                           c->divtab, c->status, c->status + 2, static_cast<const u32*>(nullptr));
+    else
+        hipLaunchKernelGGL((rcx_dec_adaptive_k<true, false>), dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)comp_size, c->h_off, (u64)1, block, count, c->h_out,
+                           c->divtab, c->status, c->status + 2, static_cast<const u32*>(nullptr));
     if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
     HIP_TRY(hipMemcpy(c->status_host, c->status, 4 * sizeof(u32), hipMemcpyDeviceToHost));
     const u32 short_at = c->status_host[2];

@@ -53,7 +53,9 @@ __device__ __forceinline__ u32 rcx_byte_of(const U4& w, u32 j)
 // STREAM = the single-stream entry point's second pass: one block, and the lane also
 // replays the reference's delayed writer to find where a bounded sink fills
 // (track[0] = failing symbol or 0xFFFFFFFF, track[1] = 1 if only the final flush fails).
-template <bool STREAM>
+// LONG = a single stream of more than RCX_MAX_BLOCK symbols: no divisor table, the lane divides by its own total and
+// halves the table at 2^24 (cpprcoder.h:1138-1176).
+template <bool STREAM, bool LONG = false>
 __global__ __launch_bounds__(64) void rcx_enc_adaptive_k(const u8* __restrict__ src, u64 n, u32 block, u64 nblocks,
                                                          u8* __restrict__ slots, u64 slot, u32* __restrict__ sizes,
                                                          const DivEntry* __restrict__ divtab, u32* status,
@@ -87,6 +89,11 @@ __global__ __launch_bounds__(64) void rcx_enc_adaptive_k(const u8* __restrict__ 
     const bool full = !STREAM && __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
     const u8* in = src + at;
 
+    if (LONG) {
+        u32 total = 256; // cpprcoder.h:1096
+        for (u32 i = 0; i < maxlen; ++i)
+            if (i < len) enc.template step_long<STREAM>(tree, in[i], total, i);
+    } else {
     DivEntry ahead = divtab[lane];
     if (full) {
         U4 cur = *reinterpret_cast<const U4*>(in);
@@ -114,6 +121,7 @@ __global__ __launch_bounds__(64) void rcx_enc_adaptive_k(const u8* __restrict__ 
                 if (i < len) enc.template step<STREAM>(tree, in[i], k, i);
             }
         }
+    }
     }
 
     if (live) {
@@ -208,7 +216,7 @@ static __device__ unsigned long long rcx_dec_stamp_out[8];
 // STREAM = the single-stream entry point: one block whose symbol count n the host took from
 // the header (max(declared,1) clipped to the sink); track[0] = first symbol whose normalize
 // ran out of input, or 0xFFFFFFFF.
-template <bool STREAM>
+template <bool STREAM, bool LONG = false>
 __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ comp, u64 comp_size, const u64* __restrict__ offsets, u64 nblocks,
                                                          u32 block, u64 n, u8* __restrict__ dst,
                                                          const DivEntry* __restrict__ divtab, u32* status, u32* track,
@@ -259,6 +267,19 @@ __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ 
     const bool full = !STREAM && __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
     u8* out = dst + at;
 
+    if (LONG) {
+        DivEntry k;
+        k.mul = k.add = k.shift = 0;
+        k.total = 256; // cpprcoder.h:1096
+        for (u32 i = 0; i < maxlen; ++i) {
+            if ((i & 15u) == 0) dec.topup();
+            if (i < len) {
+                out[i] = (u8)dec.template step<STREAM, true>(tree, k, i, stream_len);
+                k.total += 1; // cpprcoder.h:1138 (the update itself was made by step)
+                if (k.total >= RCX_HALVE_AT) k.total = tree.halve();
+            }
+        }
+    } else {
     DivEntry ahead = divtab[lane];
     if (full) {
         for (u32 i0 = 0; i0 < maxlen; i0 += RCX_STAGE) {
@@ -297,6 +318,7 @@ __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ 
                 if (i < len) out[i] = (u8)dec.template step<STREAM>(tree, k, i, stream_len);
             }
         }
+    }
     }
 #if defined(RCX_STAMP_DEC)
     if (blockIdx.x == 7 && lane == 0)

@@ -13,8 +13,11 @@
 //                  results depend only on cum(c) = sum_{i<c} f[i], so the table
 //                  is kept as a radix-4 tree of plain sums instead of the
 //                  reference's 16 chunk prefixes)
-// The table halving (cpprcoder.h:1138) needs total >= 2^24 and cannot happen
-// for block <= RCX_MAX_BLOCK.
+// The table halving (cpprcoder.h:1138-1176) needs total >= 2^24, i.e. more than
+// RCX_MAX_BLOCK = 2^24 - 256 symbols: the block kernels never see it (every lane's total
+// is 256 + the symbol index and the divisors come from a table); a single stream longer
+// than that goes through the *_long steps below: the lane keeps its own total, divides by
+// it and halves (Tree::halve).
 #pragma once
 #include <stdint.h>
 
@@ -54,6 +57,7 @@ struct alignas(16) U4 {
 #define RCX_GROUPS 85
 #define RCX_STAGE 64 /* divisor-table entries staged per refill */
 #define RCX_RING_DW 32 /* decoder: dwords of compressed stream buffered per block in LDS */
+#define RCX_HALVE_AT (1u << 24) /* cpprcoder.h:1138: the table is halved when ++total reaches MINRANGE */
 
 // One divisor-table entry for total = 256 + index:
 //   floor(n / total) == (u32)(((u64)n * mul + add) >> 32) >> shift   for all n < 2^32
@@ -119,13 +123,52 @@ struct Tree {
         v.x = v.y = v.z = v.w = 1;
         for (u32 g = RCX_G_L0; g < RCX_GROUPS; ++g) base[g * RCX_LANES] = v;
     }
-    // cpprcoder.h:1134-1177 without the (unreachable) halving: +1 on the path to the leaf.
+    // cpprcoder.h:1134-1177 without the halving: +1 on the path to the leaf.
     RCX_DEV void update(u32 c) const
     {
         bump(RCX_G_L3, c >> 6);
         bump(RCX_G_L2 + (c >> 6), (c >> 4) & 3);
         bump(RCX_G_L1 + (c >> 4), (c >> 2) & 3);
         bump(RCX_G_L0 + (c >> 2), c & 3);
+    }
+    // cpprcoder.h:1138-1176: every count becomes (f >> 1) | 1, the sums above them are rebuilt.
+    // Returns the new total.  (Once per 2^23 symbols of a very long single stream.)
+    RCX_DEV u32 halve() const
+    {
+        u32 total = 0;
+        for (u32 q3 = 0; q3 < 4; ++q3) {          // level-3 node q3 = symbols 64*q3 ..
+            U4 n2;
+            u32 sum2[4];
+            for (u32 q2 = 0; q2 < 4; ++q2) {      // level-2 node = 16 symbols
+                U4 n1;
+                u32 sum1[4];
+                for (u32 q1 = 0; q1 < 4; ++q1) {  // level-1 node = 4 symbols = one leaf group
+                    const u32 g = RCX_G_L0 + 16 * q3 + 4 * q2 + q1;
+                    U4 v = group(g);
+                    v.x = (v.x >> 1) | 1u;
+                    v.y = (v.y >> 1) | 1u;
+                    v.z = (v.z >> 1) | 1u;
+                    v.w = (v.w >> 1) | 1u;
+                    base[g * RCX_LANES] = v;
+                    sum1[q1] = v.x + v.y + v.z + v.w;
+                }
+                n1.x = sum1[0];
+                n1.y = sum1[1];
+                n1.z = sum1[2];
+                n1.w = sum1[3];
+                base[(RCX_G_L1 + 4 * q3 + q2) * RCX_LANES] = n1;
+                sum2[q2] = sum1[0] + sum1[1] + sum1[2] + sum1[3];
+            }
+            n2.x = sum2[0];
+            n2.y = sum2[1];
+            n2.z = sum2[2];
+            n2.w = sum2[3];
+            base[(RCX_G_L2 + q3) * RCX_LANES] = n2;
+            const u32 s3 = sum2[0] + sum2[1] + sum2[2] + sum2[3];
+            reinterpret_cast<u32*>(&base[RCX_G_L3 * RCX_LANES])[q3] = s3;
+            total += s3;
+        }
+        return total;
     }
 };
 
@@ -275,7 +318,12 @@ struct EncLane {
     template <bool WIDE = false>
     RCX_DEV u32 arith(u32 cum, u32 f, const DivEntry& k)
     {
-        const u32 t = rcx_div(range, k);             // cpprcoder.h:703
+        return arith_t<WIDE>(cum, f, rcx_div(range, k)); // cpprcoder.h:703
+    }
+    // the same with t = range / total in hand
+    template <bool WIDE = false>
+    RCX_DEV u32 arith_t(u32 cum, u32 f, u32 t)
+    {
         const u32 moved = low + (WIDE ? cum * t : rcx_mul24(cum, t)); // :706  (cum*t <= range < 2^32)
         const u32 carry = moved < low ? 1u : 0u;
         range = WIDE ? f * t : rcx_mul24(f, t);      // :707
@@ -344,6 +392,25 @@ struct EncLane {
         const u32 f = rcx_sel4(g0, c & 3);
         code<TRACK>(cum, f, k, index);
         tree.update(c); // :712
+    }
+
+    // The same for a stream of any length: the lane's own `total` (cpprcoder.h:1096) is the divisor, a true
+    // division, and the table is halved when the total reaches 2^24 (cpprcoder.h:1138).
+    template <bool TRACK = false, class TreeT>
+    RCX_DEV void step_long(const TreeT& tree, u32 c, u32& total, u32 index = 0)
+    {
+        const U4 g3 = tree.group(RCX_G_L3);
+        const U4 g2 = tree.group(RCX_G_L2 + (c >> 6));
+        const U4 g1 = tree.group(RCX_G_L1 + (c >> 4));
+        const U4 g0 = tree.group(RCX_G_L0 + (c >> 2));
+        const u32 cum = rcx_pre4(g3, c >> 6) + rcx_pre4(g2, (c >> 4) & 3) + rcx_pre4(g1, (c >> 2) & 3) + rcx_pre4(g0, c & 3);
+        const u32 f = rcx_sel4(g0, c & 3);
+        const u32 rec = arith_t(cum, f, range / total); // :703
+        if (TRACK) track(index, rec & 1u, rec & 0xFFFFFF00u, rec & 0x18u);
+        emit(rec);
+        tree.update(c); // :712
+        total += 1;
+        if (total >= RCX_HALVE_AT) total = tree.halve();
     }
 
     // cpprcoder.h:744-762: the held bytes, then low big-endian.  Returns the stream size.
@@ -521,8 +588,9 @@ struct DecLane {
         range <<= k8;
     }
 
-    // Decodes one symbol (one lane per block).
-    template <bool TRACK = false, class TreeT>
+    // Decodes one symbol (one lane per block).  LONG (a stream of any length): k.total is the lane's own total, the
+    // division is a true one, and the caller halves the table when the total reaches 2^24 (see EncLane::step_long).
+    template <bool TRACK = false, bool LONG = false, class TreeT>
     RCX_DEV u32 step(const TreeT& tree, const DivEntry& k, u32 index = 0, u64 stream_len = 0)
     {
         // the top two tree levels sit at fixed addresses: ask for them before anything else
@@ -534,7 +602,7 @@ struct DecLane {
         RCX_DSTAMP(1);
         if (TRACK && taken() > stream_len && short_at == 0xFFFFFFFFu) short_at = index; // cpprcoder.h:901-903
 
-        const u32 t = rcx_div(range, k); // :904
+        const u32 t = LONG ? range / k.total : rcx_div(range, k); // :904
         const u32 top = rcx_mul24(k.total, t);
         u32 rem = low, c = 0, p, hit;
         U4 g = g3;

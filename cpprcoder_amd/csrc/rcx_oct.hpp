@@ -751,14 +751,18 @@ template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restrict__ comp, u64 comp_size, const u64* __restrict__ offsets,
                                                              u64 nblocks, u32 block, u64 n, u8* __restrict__ dst,
                                                              const DivEntry* __restrict__ divtab, u32* status,
-                                                             u32* __restrict__ redo)
+                                                             u32* __restrict__ redo, u32 quads_used)
 {
     __shared__ __attribute__((aligned(256))) u8 lds_all[WAVES * RCX_QUAD_LDS_BYTES];
     const u32 lane = threadIdx.x & 63u;
     const u32 wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     u8* lds = lds_all + wave_in_wg * RCX_QUAD_LDS_BYTES;
     const u32 j = lane & 3u, quad = lane >> 2;
-    const u64 blk = ((u64)blockIdx.x * WAVES + wave_in_wg) * RCX_QUAD_BLOCKS + quad;
+    // quads_used (1, 2, 4, 8 or 16) of the wave's 16 quads carry a block (rcx_api.hip picks it from the block count
+    // so that every SIMD of the machine has a wave before any wave carries 16 blocks).  The other quads decode
+    // the block of quad (quad mod quads_used) along with it -- same instructions, well-defined state -- and store nothing.
+    const bool in_use = quad < quads_used;
+    const u64 blk = ((u64)blockIdx.x * WAVES + wave_in_wg) * quads_used + (quad & (quads_used - 1u));
     bool live = blk < nblocks;
     const u64 at = live ? blk * (u64)block : 0;
     u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
@@ -787,13 +791,13 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
         const u64 s0 = offsets[blk], s1 = offsets[blk + 1];
         stream_len = s1 - s0;
         if (s1 < s0 || s1 > comp_size || stream_len < 9) {
-            if (j == 0) rcx_flag(status, RCX_ST_CORRUPT, blk);
+            if (j == 0 && in_use) rcx_flag(status, RCX_ST_CORRUPT, blk);
             live = false;
             len = 0;
         } else {
             const u32 declared = in.begin(comp + s0, comp + s1, block_ring, parked + 3);
             if (declared != len) {
-                if (j == 0) rcx_flag(status, RCX_ST_CORRUPT, blk);
+                if (j == 0 && in_use) rcx_flag(status, RCX_ST_CORRUPT, blk);
                 live = false;
                 len = 0;
             }
@@ -804,7 +808,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
     const u32 maxlen = rcx_wave_max(len);
     const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
     u8* out = dst + at;
-    const bool leader = live && j == 0;
+    const bool leader = live && in_use && j == 0;
 
     // One symbol; the owning lane ORs it into WORD at bit SHIFT (the quad's other lanes OR in 0).
     //
@@ -1060,7 +1064,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
     const bool marked = live && rcx_quad_or(j == 3 && U4_ != 256u + len ? 1u : 0u) != 0;
     if (leader && !marked && in.taken() > stream_len) rcx_flag(status, RCX_ST_CORRUPT, blk);
     if (leader) redo[blk] = marked ? 1u : 0u;
-    else if (j == 0 && blk < nblocks) redo[blk] = 0;
+    else if (j == 0 && in_use && blk < nblocks) redo[blk] = 0;
 }
 
 // ===========================================================================
@@ -1337,12 +1341,15 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
 __global__ __launch_bounds__(RCX_MC5_THREADS) void rcx_enc_mc5_k(const u8* __restrict__ src, u64 n, u32 block, u64 nblocks,
                                                                 u8* __restrict__ slots, u64 slot, u32* __restrict__ sizes,
                                                                 const DivEntry* __restrict__ divtab, u32* status,
-                                                                u32* __restrict__ redo)
+                                                                u32* __restrict__ redo, u32 lanes_used)
 {
     __shared__ U4 lds[RCX_MC5_LDS_U4];
     const u32 lane = threadIdx.x & 63u;
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const u64 blk = (u64)blockIdx.x * RCX_LANES + lane;
+    // lanes_used (1..64) of the 64 lanes carry a block; the others idle along (rcx_api.hip picks it from the
+    // block count so that every CU has a workgroup before any workgroup carries 64 blocks)
+    const bool in_use = lane < lanes_used;
+    const u64 blk = in_use ? (u64)blockIdx.x * lanes_used + lane : nblocks;
     const bool live = blk < nblocks;
     const u64 at = live ? blk * (u64)block : 0;
     const u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
@@ -1358,12 +1365,12 @@ __global__ __launch_bounds__(RCX_MC5_THREADS) void rcx_enc_mc5_k(const u8* __res
     u32* out_drained = out_pos + RCX_LANES;    // drain -> writer's finish: bytes stored so far
 
     const u32 maxlen = rcx_wave_max(len);
-    const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
-    const u8* in = src + at;
+    const bool full = __all(!in_use || (live && len == block)) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+    const u8* in = src + at; // (a lane without a block reads the first block along)
     const u32 nchunks = (maxlen + RCX_MC_CHUNK - 1) / RCX_MC_CHUNK;
 
     EncLane enc;
-    u8* wave_slots = slots + (u64)blockIdx.x * RCX_LANES * slot;
+    u8* wave_slots = slots + (u64)blockIdx.x * lanes_used * slot;
     enc.idle(wave_slots); // wave 0 uses low/range; wave 1 takes over for finish()
     StagedWriter wr;
     wr.begin(out_ring, out_dummy, lane);

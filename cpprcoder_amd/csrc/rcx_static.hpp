@@ -39,6 +39,59 @@ struct StaticTable {
     }
 };
 
+
+// count() (cpprcoder.h:543-571) for the symbols [from, to) of every lane's block, with the order-dependent 16-bit
+// squeeze (:549-555): when a count is 0xFFFF or more BEFORE its increment, every non-zero count becomes
+// (c >> 1) | 1 first.  PIECES: the blocks are whole and 16-byte aligned and `from` is a multiple of 16, so the input
+// is taken 16 bytes at a time: the 16 increments are issued as returning LDS atomics, and only if one of them
+// found 0xFFFF or more (a block dominated by one symbol) are they taken back and redone one by one.
+__device__ __forceinline__ void rcx_static_squeeze(const StaticTable& tab)
+{
+    for (u32 q = 0; q < 256; ++q) {
+        const u32 c = tab.get(q);
+        if (c > 0) tab.set(q, (c >> 1) | 1u);
+    }
+}
+__device__ __forceinline__ void rcx_static_count_one(const StaticTable& tab, u32 b)
+{
+    if (tab.get(b) >= 0xFFFFu) rcx_static_squeeze(tab);
+    tab.set(b, tab.get(b) + 1);
+}
+template <bool PIECES>
+__device__ __forceinline__ void rcx_static_count_checked(const StaticTable& tab, const u8* in, u32 from, u32 to, u32 len)
+{
+    u32 i = from;
+    if (PIECES) {
+        for (; i + 16 <= to; i += 16) {
+            const U4 piece = *reinterpret_cast<const U4*>(in + i);
+            u32 worst = 0;
+#pragma unroll
+            for (u32 s = 0; s < 16; ++s) {
+                const u32 old = __hip_atomic_fetch_add(tab.col + rcx_byte_of(piece, s) * RCX_LANES, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                worst = worst > old ? worst : old;
+            }
+            if (rcx_any(worst >= 0xFFFFu)) {
+                if (worst >= 0xFFFFu) {
+                    for (u32 s = 0; s < 16; ++s) tab.set(rcx_byte_of(piece, s), tab.get(rcx_byte_of(piece, s)) - 1);
+                    for (u32 s = 0; s < 16; ++s) rcx_static_count_one(tab, rcx_byte_of(piece, s));
+                }
+            }
+        }
+    }
+    for (; i < to; ++i)
+        if (i < len) rcx_static_count_one(tab, in[i]);
+}
+// The largest count of the lane's table: no squeeze can fire while it stays below 0xFFFF.
+__device__ __forceinline__ u32 rcx_static_max_count(const StaticTable& tab)
+{
+    u32 m = 0;
+    for (u32 q = 0; q < 256; ++q) {
+        const u32 c = tab.get(q);
+        m = m > c ? m : c;
+    }
+    return m;
+}
+
 // ===========================================================================
 // Static encode, pass 1 (scan + scatter are shared with the adaptive coder)
 // ===========================================================================
@@ -79,19 +132,26 @@ __global__ __launch_bounds__(64) void rcx_enc_static_k(const u8* __restrict__ sr
         for (u32 i = 0; i < easy; ++i)
             if (i < len) tab.inc(in[i]);
     }
-    for (u32 i = easy; i < maxlen; ++i) {
-        if (i < len) {
-            const u32 b = in[i];
-            if (tab.get(b) >= 0xFFFFu) { // :549-555: every non-zero count becomes (c >> 1) | 1
-                for (u32 q = 0; q < 256; ++q) {
-                    const u32 c = tab.get(q);
-                    if (c > 0) tab.set(q, (c >> 1) | 1u);
-                }
-            }
-            tab.set(b, tab.get(b) + 1);
+    if (full) {
+        const u32 from = (easy + 15u) & ~15u;
+        rcx_static_count_checked<false>(tab, in, easy, from < maxlen ? from : maxlen, len);
+        if (from < maxlen) rcx_static_count_checked<true>(tab, in, from, maxlen, len);
+    } else {
+        rcx_static_count_checked<false>(tab, in, easy, maxlen, len);
+    }
+    // The second rescale of count() (cpprcoder.h:561-570): more than 2^24 symbols (single streams only: blocks are
+    // at most RCX_MAX_BLOCK).  Entry 0 is skipped, as the reference's loop starting at 1 does.
+    if (len > (1u << 24)) {
+        u32 sz = len, shift = 0;
+        while (sz > (1u << 24)) {
+            sz >>= 1;
+            ++shift;
+        }
+        for (u32 q = 1; q < 256; ++q) {
+            const u32 c = tab.get(q);
+            tab.set(q, c != 0 ? ((c >> shift) | 1u) : 0u);
         }
     }
-    // (the second rescale of count(), cpprcoder.h:561-570, needs n > 2^24: unreachable for RCX_MAX_BLOCK)
 
     // ---- header: u32 LE n + 256 u16 counts (cpprcoder.h:386-397, :604-619), then the cumulative table ----
     u8* wave_slots = slots + (u64)blockIdx.x * RCX_LANES * slot;
@@ -250,12 +310,13 @@ __device__ __forceinline__ void rcx_static3_pipeline(u32 wave, u32 lane, u32 len
 
 __global__ __launch_bounds__(RCX_ST3_THREADS) void rcx_enc_static3_k(const u8* __restrict__ src, u64 n, u32 block, u64 nblocks,
                                                                     u8* __restrict__ slots, u64 slot, u32* __restrict__ sizes,
-                                                                    u32* status, u32* __restrict__ redo)
+                                                                    u32* status, u32* __restrict__ redo, u32 lanes_used)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[RCX_ST3_LDS_DW];
     const u32 lane = threadIdx.x & 63u;
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const u64 blk = (u64)blockIdx.x * RCX_LANES + lane;
+    const bool in_use = lane < lanes_used; // see rcx_enc_mc5_k
+    const u64 blk = in_use ? (u64)blockIdx.x * lanes_used + lane : nblocks;
     const bool live = blk < nblocks;
     const u64 at = live ? blk * (u64)block : 0;
     const u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
@@ -270,7 +331,7 @@ __global__ __launch_bounds__(RCX_ST3_THREADS) void rcx_enc_static3_k(const u8* _
     u32* out_drained = out_pos + RCX_LANES;
 
     const u32 maxlen = rcx_wave_max(len);
-    const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+    const bool full = __all(!in_use || (live && len == block)) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
     const u32 nchunks = (maxlen + RCX_MC_CHUNK - 1) / RCX_MC_CHUNK;
 
     // ---- count(), cpprcoder.h:543-571 ----
@@ -290,26 +351,46 @@ __global__ __launch_bounds__(RCX_ST3_THREADS) void rcx_enc_static3_k(const u8* _
         for (u32 s = 0; s < 16; ++s) tab.inc(rcx_byte_of(piece, s));
     }
     rcx_lds_barrier();
-    if (wave == 0) {
-        for (u32 i = easy16; i < easy; ++i)
-            if (i < len) tab.inc(in[i]);
-        for (u32 i = easy; i < maxlen; ++i) {
-            if (i < len) {
-                const u32 b = in[i];
-                if (tab.get(b) >= 0xFFFFu) { // :549-555: every non-zero count becomes (c >> 1) | 1
-                    for (u32 q = 0; q < 256; ++q) {
-                        const u32 c = tab.get(q);
-                        if (c > 0) tab.set(q, (c >> 1) | 1u);
-                    }
-                }
-                tab.set(b, tab.get(b) + 1);
+    if (easy < maxlen) {
+        // Past symbol 65535.  If no count can reach 0xFFFF before the block ends (largest count so far + the
+        // symbols left: every wave computes the same answer from the same table) the three waves go on as
+        // before; otherwise the order matters and wave 0 counts the rest alone, in order, with the test.
+        const u32 mx = rcx_static_max_count(tab);
+        const bool calm = __all(mx + (len > easy16 ? len - easy16 : 0u) < 0xFFFFu);
+        rcx_lds_barrier(); // (wave 0 may not start changing the table while another wave still reads it)
+        if (wave == 0) {
+            for (u32 i = easy16; i < easy; ++i)
+                if (i < len) tab.inc(in[i]);
+        }
+        if (calm && full) {
+            const u32 from = (easy + 15u) & ~15u; // 65536
+            const u32 to16 = maxlen & ~15u;
+            if (wave == 0)
+                for (u32 i = easy; i < from && i < maxlen; ++i) tab.inc(in[i]);
+            for (u32 i = from + 16 * wave; i < to16; i += 48) {
+                const U4 piece = *reinterpret_cast<const U4*>(in + i);
+#pragma unroll
+                for (u32 s = 0; s < 16; ++s) tab.inc(rcx_byte_of(piece, s));
+            }
+            if (wave == 0)
+                for (u32 i = (to16 > from ? to16 : from); i < maxlen; ++i) tab.inc(in[i]);
+        } else if (wave == 0) {
+            if (full) {
+                const u32 from = (easy + 15u) & ~15u;
+                rcx_static_count_checked<false>(tab, in, easy, from < maxlen ? from : maxlen, len);
+                if (from < maxlen) rcx_static_count_checked<true>(tab, in, from, maxlen, len);
+            } else {
+                rcx_static_count_checked<false>(tab, in, easy, maxlen, len);
             }
         }
+    } else if (wave == 0) {
+        for (u32 i = easy16; i < easy; ++i)
+            if (i < len) tab.inc(in[i]);
     }
     rcx_lds_barrier();
 
     // ---- header: u32 LE n + 256 u16 counts (cpprcoder.h:386-397, :604-619) ----
-    u8* wave_slots = slots + (u64)blockIdx.x * RCX_LANES * slot;
+    u8* wave_slots = slots + (u64)blockIdx.x * lanes_used * slot;
     EncLane enc;
     enc.idle(wave_slots);
     StagedWriter wr;
@@ -520,14 +601,15 @@ __global__ __launch_bounds__(64) void rcx_dec_static_k(const u8* __restrict__ co
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void rcx_dec_static_quad_k(const u8* __restrict__ comp, u64 comp_size, const u64* __restrict__ offsets,
                                                                     u64 nblocks, u32 block, u64 n, u8* __restrict__ dst,
-                                                                    u32* status, u32* __restrict__ redo)
+                                                                    u32* status, u32* __restrict__ redo, u32 quads_used)
 {
     __shared__ __attribute__((aligned(256))) u8 lds_all[WAVES * RCX_SQUAD_LDS_BYTES];
     const u32 lane = threadIdx.x & 63u;
     const u32 wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     u8* lds = lds_all + wave_in_wg * RCX_SQUAD_LDS_BYTES;
     const u32 j = lane & 3u, quad = lane >> 2;
-    const u64 blk = ((u64)blockIdx.x * WAVES + wave_in_wg) * RCX_QUAD_BLOCKS + quad;
+    const bool in_use = quad < quads_used; // see rcx_dec_quad_k: the other quads decode along and store nothing
+    const u64 blk = ((u64)blockIdx.x * WAVES + wave_in_wg) * quads_used + (quad & (quads_used - 1u));
     bool live = blk < nblocks;
     const u64 at = live ? blk * (u64)block : 0;
     u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
@@ -575,7 +657,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_static_quad_k(const u8* __
             in.begin(s + RCX_STATIC_HEADER - 3, comp + s1, block_ring, parked + 3);
             in.range = 0xFFFFFFFFu;
         } else {
-            if (j == 0) rcx_flag(status, RCX_ST_CORRUPT, blk);
+            if (j == 0 && in_use) rcx_flag(status, RCX_ST_CORRUPT, blk);
             live = false;
             len = 0;
         }
@@ -598,7 +680,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_static_quad_k(const u8* __
     const u32 maxlen = rcx_wave_max(len);
     const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
     u8* out = dst + at;
-    const bool leader = live && j == 0;
+    const bool leader = live && in_use && j == 0;
     const u32 leaves_lds = (u32)reinterpret_cast<uintptr_t>(leaves);
     u32 worst_node = 0;            // 16 = a target past the table
     u32 least_range = 0xFFFFFFFFu; // 0 = a symbol of count 0
@@ -735,5 +817,5 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_static_quad_k(const u8* __
     const bool marked = live && (worst_node >= 16u || least_range == 0);
     if (leader && !marked && in.taken() + (RCX_STATIC_HEADER - 3) > stream_len) rcx_flag(status, RCX_ST_CORRUPT, blk);
     if (leader) redo[blk] = marked ? 1u : 0u;
-    else if (j == 0 && blk < nblocks) redo[blk] = 0;
+    else if (j == 0 && in_use && blk < nblocks) redo[blk] = 0;
 }

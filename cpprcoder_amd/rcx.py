@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("RCX_LIBRARY") or os.path.join(HERE, "librcx.so")  # R
 OK, PENDING, ERROR, E_ARG, E_CAPACITY, E_CORRUPT, E_HIP, E_NOMEM = 0, 1, -1, -2, -3, -4, -5, -6
 CODER_ADAPTIVE, CODER_STATIC = 0, 1
 T_ENCODE, T_SCAN, T_SCATTER, T_DECODE, T_COUNT = 0, 1, 2, 3, 4
-MIN_BLOCK, MAX_BLOCK = 16, 1 << 20
+MIN_BLOCK, MAX_BLOCK, MAX_STREAM = 16, (1 << 24) - 256, 0x7FFFFFFF
 
 # every symbol include/rcx.h declares (tests check that the library exports all of them)
 EXPORTS = (
@@ -63,7 +63,7 @@ def lib() -> C.CDLL:
         L.rcx_decode_blocks.restype = i32
         L.rcx_decode_blocks.argtypes = [vp, i32, vp, u64, vp, u64, u32, vp, u64, C.POINTER(u64)]
         L.rcx_stream_encode.restype = i32
-        L.rcx_stream_encode.argtypes = [vp, i32, vp, u32, vp, u64, C.POINTER(u64), C.POINTER(u32)]
+        L.rcx_stream_encode.argtypes = [vp, i32, vp, u32, vp, u64, u64, C.POINTER(u64), C.POINTER(u32)]
         L.rcx_stream_decode.restype = i32
         L.rcx_stream_decode.argtypes = [vp, i32, vp, u64, vp, u64, C.POINTER(u64), C.POINTER(u32)]
         L.rcx_ctx_set_timing.restype, L.rcx_ctx_set_timing.argtypes = i32, [vp, i32]
@@ -180,14 +180,19 @@ class Context:
         return out[: size.value].copy()
 
     # ---- single streams (reference semantics, used by the C++ facade) ------
-    def stream_encode(self, data, sink_capacity: int | None = None, coder: int = CODER_ADAPTIVE):
-        """-> (status, request_size, stream bytes)"""
+    def stream_encode(self, data, sink_capacity: int | None = None, coder: int = CODER_ADAPTIVE, dst_cap: int | None = None):
+        """-> (status, request_size, stream bytes).  dst_cap: size of the buffer handed to the library (default: exactly
+        what include/rcx.h says is needed, with canary bytes behind it that must survive)."""
         src = _np_u8(data)
-        cap = (len(src) + len(src) // 32 + 1024) if sink_capacity is None else sink_capacity
-        dst = np.zeros(max(cap, 16) + 64, dtype=np.uint8)
+        bound = block_bound(max(len(src), MIN_BLOCK))
+        cap = bound if sink_capacity is None else sink_capacity
+        room = min(max(cap, 4) + 4, bound) if dst_cap is None else dst_cap
+        dst = np.full(room + 64, 0xA5, dtype=np.uint8)
         size, req = C.c_uint64(), C.c_uint32()
-        st = lib().rcx_stream_encode(self._h, coder, src.ctypes.data, len(src), dst.ctypes.data, cap, C.byref(size), C.byref(req))
-        return st, req.value, bytes(dst[: size.value])
+        st = lib().rcx_stream_encode(self._h, coder, src.ctypes.data, len(src), dst.ctypes.data, room, cap, C.byref(size), C.byref(req))
+        if not bool((dst[room:] == 0xA5).all()):
+            raise AssertionError("rcx_stream_encode wrote past dst_cap")
+        return st, req.value, bytes(dst[: min(size.value, room)]) if st in (OK, PENDING) else b""
 
     def stream_decode(self, comp, sink_capacity: int, coder: int = CODER_ADAPTIVE):
         src = _np_u8(comp)

@@ -22,7 +22,8 @@
  *   - One stream is one GPU lane: this facade is for drop-in compatibility.  Throughput
  *     comes from coding many blocks at once through rcx_encode_blocks_device (rcx.h),
  *     see BlockCoder below.
- *   - Streams longer than RCX_MAX_BLOCK (1 MiB) return Status_Error.
+ *   - Streams may be as long as the reference's (MAX_SIZE = 0x7FFFFFFF); past 2^24 - 256 symbols the GPU lane
+ *     halves its table as cpprcoder.h:1138-1176 does.
  */
 #ifndef INC_CPPRCODER_AMD_FACADE_H_
 #define INC_CPPRCODER_AMD_FACADE_H_
@@ -228,7 +229,7 @@ private:
         std::vector<u8> out(static_cast<size_t>(rcx_block_bound(n < RCX_MIN_BLOCK ? RCX_MIN_BLOCK : n)) + 64);
         uint64_t size = 0;
         uint32_t req = 0;
-        if (rcx_stream_encode(ctx, RCX_CODER_ADAPTIVE, input_.data(), n, out.data(), out.size(), &size, &req) != RCX_OK)
+        if (rcx_stream_encode(ctx, RCX_CODER_ADAPTIVE, input_.data(), n, out.data(), out.size(), out.size(), &size, &req) != RCX_OK)
             return {Status_Error, 0};
         // Replay the reference's sink calls: payload byte by byte through writeByte (never grows),
         // the last four bytes through write (may grow) -- cpprcoder.h:744-762, 783-800.
@@ -239,7 +240,7 @@ private:
                 // Which symbol was being coded when byte i did not fit?  Ask the device to replay the
                 // reference's delayed writer against a sink that accepts exactly i bytes.
                 uint64_t size2 = 0;
-                int st = rcx_stream_encode(ctx, RCX_CODER_ADAPTIVE, input_.data(), n, out.data(), i, &size2, &req);
+                int st = rcx_stream_encode(ctx, RCX_CODER_ADAPTIVE, input_.data(), n, out.data(), out.size(), i, &size2, &req);
                 if (st == RCX_PENDING) {
                     inSize_ = n - req;
                     return {Status_Pending, req}; // cpprcoder.h:708-711
@@ -324,10 +325,10 @@ public:
     {
         CPPRCODER_ASSERT(size <= MAX_SIZE);
         rcx_ctx* ctx = facade_context();
-        if (!ctx || RCX_MAX_BLOCK < size) return false;
+        if (!ctx || RCX_MAX_STREAM < size) return false;
         std::vector<u8> out(static_cast<size_t>(rcx_block_bound(size < RCX_MIN_BLOCK ? RCX_MIN_BLOCK : size)) + 64);
         uint64_t total = 0;
-        if (rcx_stream_encode(ctx, RCX_CODER_STATIC, bytes, size, out.data(), out.size(), &total, nullptr) != RCX_OK) return false;
+        if (rcx_stream_encode(ctx, RCX_CODER_STATIC, bytes, size, out.data(), out.size(), out.size(), &total, nullptr) != RCX_OK) return false;
         if (stream.write(4, out.data()) <= 0) return false;
         for (u32 i = 0; i < 4; ++i) { // write16(): 4 x 64 counts (cpprcoder.h:604-619)
             if (stream.write(128, out.data() + 4 + 128 * i) <= 0) return false;

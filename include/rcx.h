@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define RCX_VERSION 100 /* 0.1.0 */
+#define RCX_VERSION 200 /* 0.2.0 */
 
 /* Status codes.  0 / 1 / -1 are the reference's Status enum (cpprcoder.h:112-117). */
 enum {
@@ -63,7 +63,12 @@ enum {
 };
 
 #define RCX_MIN_BLOCK 16u
-#define RCX_MAX_BLOCK (1u << 20) /* the GPU kernels never need the table halving of cpprcoder.h:1138 below 2^24-256 symbols */
+/* Largest block of the many-block calls: the last size at which the table halving of cpprcoder.h:1138-1176 cannot
+ * happen (the total starts at 256 and the halving comes when ++total reaches 2^24), so every block's i-th symbol
+ * sees total = 256 + i.  Single streams (rcx_stream_*) may be longer, up to RCX_MAX_STREAM = the reference's
+ * MAX_SIZE (cpprcoder.h:329): past RCX_MAX_BLOCK symbols the lane keeps its own total and halves the table. */
+#define RCX_MAX_BLOCK ((1u << 24) - 256u)
+#define RCX_MAX_STREAM 0x7FFFFFFFu
 
 typedef struct rcx_ctx rcx_ctx;
 
@@ -123,20 +128,24 @@ int rcx_decode_blocks(rcx_ctx* ctx, int coder, const uint8_t* comp, uint64_t com
 
 /*
  * Single-stream calls with the reference's exact stream semantics, used by the
- * C++ facade: one stream = one block of any size 0 .. RCX_MAX_BLOCK.
+ * C++ facade: one stream of any size 0 .. RCX_MAX_STREAM, coded by one GPU lane.
  *   rcx_stream_encode == initialize(sink, n); encode(n, src)  into a sink that holds
  *       exactly sink_capacity bytes before writeByte fails (for a MemoryStream that is
  *       its capacity(), i.e. the constructor argument rounded up to 16, cpprcoder.h:975):
- *       returns RCX_OK, or RCX_PENDING with *request_size set as cpprcoder.h:708-711
- *       does when the sink fills (dst then holds the sink_capacity bytes written so far).
- *       dst must have room for min(sink_capacity, rcx_block_bound(n)) bytes.
+ *       returns RCX_OK with the whole stream in dst (*dst_size bytes: everything that fit through
+ *       writeByte plus the final write(4), which grows the sink -- up to sink_capacity + 4), or
+ *       RCX_PENDING with *request_size set as cpprcoder.h:708-711 does when the sink fills
+ *       (dst then holds the max(sink_capacity, 4) bytes written so far).  dst holds dst_cap bytes;
+ *       if the bytes to hand back do not fit, nothing is copied, *dst_size says how many there
+ *       are and the call returns RCX_E_CAPACITY.  rcx_block_bound(n) is always enough.
  *   rcx_stream_decode == initialize(sink); decode(comp_size, comp): RCX_OK,
  *       RCX_PENDING (+ request_size) for short input or a full sink (one that accepts
  *       sink_capacity bytes), including the
  *       reference's quirk that a stream declaring 0 bytes yields one byte (cpprcoder.h:912).
+ *       dst must have room for min(max(declared, 1), sink_capacity) bytes.
  */
 int rcx_stream_encode(rcx_ctx* ctx, int coder, const uint8_t* src, uint32_t n,
-                      uint8_t* dst, uint64_t sink_capacity, uint64_t* dst_size, uint32_t* request_size);
+                      uint8_t* dst, uint64_t dst_cap, uint64_t sink_capacity, uint64_t* dst_size, uint32_t* request_size);
 int rcx_stream_decode(rcx_ctx* ctx, int coder, const uint8_t* comp, uint64_t comp_size,
                       uint8_t* dst, uint64_t sink_capacity, uint64_t* dst_size, uint32_t* request_size);
 

@@ -21,7 +21,9 @@ def golden():
         kat = json.load(f)
     with open(os.path.join(here, "blocks.json")) as f:
         blocks = json.load(f)["blocks"]
-    return {"kat": kat, "blocks": blocks}
+    with open(os.path.join(here, "long_streams.json")) as f:
+        long_streams = json.load(f)
+    return {"kat": kat, "blocks": blocks, "long": long_streams}
 
 
 @pytest.fixture(scope="session")

@@ -70,7 +70,7 @@ class Checker:
     # ---- one-shot streams -------------------------------------------------
     @staticmethod
     def default_capacity(n: int) -> int:
-        return n + n // 32 + 1024
+        return n + n // 32 + 1024 + (n // 8 if n > (1 << 20) else 0)
 
     def _oneshot(self, fn, data, sink_capacity, *mid):
         src = _u8(data)
@@ -110,7 +110,7 @@ class Checker:
     # ---- many blocks ------------------------------------------------------
     @staticmethod
     def block_bound(block: int) -> int:
-        b = block + block // 32 + 1024
+        b = block + block // 32 + 1024 + (block // 8 if block > (1 << 20) else 0)
         return (b + 15) & ~15
 
     def encode_blocks(self, data, block: int, coder: int = 0, threads: int = 1):

@@ -111,6 +111,46 @@ uint32_t sim_stream_decode_track(const uint8_t* comp, uint64_t comp_size, uint32
     return d.short_at;
 }
 
+// One stream of any length through the *_long steps (the lane's own total, true division, halving at 2^24:
+// what rcx_stream_encode / rcx_stream_decode run past RCX_MAX_BLOCK symbols).  Returns the stream size.
+uint32_t sim_stream_encode_long(const uint8_t* src, uint32_t n, uint8_t* slot, uint64_t slot_bytes)
+{
+    std::vector<U4> lds((RCX_GROUPS + 1) * RCX_LANES);
+    Tree tree{lds.data() + 11};
+    tree.reset();
+    EncLane e;
+    e.begin(slot, 0, (u32)slot_bytes, n);
+    u32 total = 256;
+    for (uint32_t i = 0; i < n; ++i) e.step_long(tree, src[i], total, i);
+    const uint32_t size = e.finish();
+    return e.overflow ? 0 : size;
+}
+
+uint32_t sim_stream_decode_long(const uint8_t* comp, uint64_t comp_size, uint32_t count, uint8_t* dst)
+{
+    std::vector<U4> lds((RCX_GROUPS + 1) * RCX_LANES);
+    Tree tree{lds.data() + 12};
+    tree.reset();
+    std::vector<uint8_t> pad(comp_size + 64);
+    uint8_t* base = pad.data();
+    while (((uintptr_t)base & 15) != 0) ++base;
+    base += 16 + 3;
+    memcpy(base, comp, comp_size);
+    std::vector<u32> ringmem(RCX_RING_DW * RCX_LANES);
+    DecLane d;
+    d.begin(base, base + comp_size, ringmem.data() + 12);
+    DivEntry k;
+    k.mul = k.add = k.shift = 0;
+    k.total = 256;
+    for (uint32_t i = 0; i < count; ++i) {
+        if ((i & 15u) == 0) d.topup();
+        dst[i] = (uint8_t)d.step<true, true>(tree, k, i, comp_size);
+        k.total += 1;
+        if (k.total >= RCX_HALVE_AT) k.total = tree.halve();
+    }
+    return d.short_at;
+}
+
 // comp/offsets as the encoder's compacted output.  Returns 0, or 1 + index of the first bad block.
 uint64_t sim_decode_blocks(const uint8_t* comp, const uint64_t* offsets, uint64_t nblocks, uint32_t block, uint64_t n, uint8_t* dst, uint32_t lane)
 {

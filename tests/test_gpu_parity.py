@@ -179,7 +179,7 @@ def test_errors_are_reported_not_fatal(ctx, oracle):
     with pytest.raises(rcx.RcxError):
         ctx.encode_blocks_device(src, 8, dst, offs)  # block size out of range
     with pytest.raises(rcx.RcxError):
-        ctx.encode_blocks_device(src, (1 << 20) + 16, dst, offs)
+        ctx.encode_blocks_device(src, rcx.MAX_BLOCK + 16, dst, offs)  # a block the halving could reach (cpprcoder.h:1138)
 
 
 def test_corrupt_payload_decodes_like_the_reference(ctx, oracle):
@@ -441,7 +441,7 @@ def test_every_kernel_variant_is_bit_identical(oracle):
     import os
     from cpprcoder_amd import rcx
     data = workloads.canterbury_tiled(65536 * 37 + 4321)
-    saved = {k: os.environ.get(k) for k in ("RCX_ENC_VARIANT", "RCX_LANES_PER_BLOCK")}
+    saved = {k: os.environ.get(k) for k in ("RCX_ENC_VARIANT", "RCX_LANES_PER_BLOCK", "RCX_ENC_LANES", "RCX_DEC_QUADS")}
     try:
         for block in (4096, 65536):
             slots, sizes = oracle.encode_blocks(data, block, threads=8)
@@ -455,6 +455,21 @@ def test_every_kernel_variant_is_bit_identical(oracle):
                     back, st, _ = gpu_decode(c, payload, offsets, len(data), block)
                     assert st == 0 and np.array_equal(back, data), (block, dec)
                     c.close()
+            # launch shapes (rcx_api.hip: encode_lanes / decode_quads): fewer blocks per workgroup / per wave
+            for lanes, quads in (("1", "1"), ("8", "4"), ("32", "8"), ("5", "2")):
+                os.environ["RCX_ENC_VARIANT"], os.environ["RCX_LANES_PER_BLOCK"] = "3", "4"
+                os.environ["RCX_ENC_LANES"], os.environ["RCX_DEC_QUADS"] = lanes, quads
+                c = rcx.Context(0)
+                for coder, want_p, want_o in ((0, ref_payload, ref_offsets), (1, None, None)):
+                    if coder == 1:
+                        s_slots, s_sizes = oracle.encode_blocks(data, block, coder=1, threads=8)
+                        want_p, want_o = oracle.compact(s_slots, s_sizes)
+                    payload, offsets, _ = gpu_encode(c, data, block, coder=coder)
+                    assert np.array_equal(payload, want_p) and np.array_equal(offsets, want_o), (block, lanes, coder)
+                    back, st, _ = gpu_decode(c, payload, offsets, len(data), block, coder=coder)
+                    assert st == 0 and np.array_equal(back, data), (block, quads, coder)
+                c.close()
+                os.environ.pop("RCX_ENC_LANES"), os.environ.pop("RCX_DEC_QUADS")
             # static coder: one-wave / three-wave encoder x one-lane / four-lane decoder
             s_slots, s_sizes = oracle.encode_blocks(data, block, coder=1, threads=8)
             s_payload, s_offsets = oracle.compact(s_slots, s_sizes)
@@ -528,3 +543,95 @@ def test_many_small_random_buffers(ctx, oracle):
         assert_same_blocks(payload, offsets, slots, sizes)
         back, st, _ = gpu_decode(ctx, payload, offsets, n, block, coder=coder, comp_offset=int(rs.randint(16)))
         assert st == 0 and np.array_equal(back, data), (block, n, alpha, coder)
+
+
+# ---------------------------------------------------------------------------
+# Past 1 MiB: big blocks (no halving up to RCX_MAX_BLOCK = 2^24 - 256) and long single streams through the
+# halving at total = 2^24 (cpprcoder.h:1138-1176); fixtures from the reference (tests/golden/make_golden_long.py)
+# ---------------------------------------------------------------------------
+def test_blocks_past_one_mebibyte(ctx, golden):
+    for t in golden["long"]["blocks"]:
+        coder = 0 if t["coder"] == "adaptive" else 1
+        data = workloads.by_name(t["workload"], t["n"], t["seed"])
+        assert hashlib.sha256(data.tobytes()).hexdigest() == t["input_sha256"]
+        payload, offsets, _ = gpu_encode(ctx, data, t["block"], coder=coder)
+        assert [int(x) for x in np.diff(offsets.astype(np.int64))] == t["sizes"], (t["workload"], t["block"], t["coder"])
+        fnv = ["%016x" % oracle_lib.fnv1a64(payload[int(offsets[b]): int(offsets[b + 1])]) for b in range(len(t["sizes"]))]
+        assert fnv == t["fnv1a64"], (t["workload"], t["block"], t["coder"])
+        back, st, _ = gpu_decode(ctx, payload, offsets, t["n"], t["block"], coder=coder)
+        assert st == 0 and np.array_equal(back, data)
+
+
+def test_block_of_the_largest_size(ctx, golden):
+    """One block of RCX_MAX_BLOCK = 2^24 - 256 symbols: the last size whose table is never halved, through the
+    many-lane kernels (divisor table built on the device up to total 2^24)."""
+    from cpprcoder_amd import rcx
+    g = golden["long"]["adaptive"]["zipf(NO_HALVING,4)"]
+    data = workloads.zipf(rcx.MAX_BLOCK, 4)
+    assert hashlib.sha256(data.tobytes()).hexdigest() == g["input_sha256"]
+    payload, offsets, _ = gpu_encode(ctx, data, rcx.MAX_BLOCK)
+    assert len(payload) == g["size"] and hashlib.sha256(payload.tobytes()).hexdigest() == g["sha256"]
+    back, st, _ = gpu_decode(ctx, payload, offsets, len(data), rcx.MAX_BLOCK)
+    assert st == 0 and np.array_equal(back, data)
+
+
+def test_long_single_streams(ctx, golden):
+    """rcx_stream_encode / rcx_stream_decode on streams of 2 MiB ... 2^24 + 70000 symbols: the reference's bytes
+    (cpprcoder.h:697-720 has no size cap), including the halve-and-resum step (cpprcoder.h:1138-1176) and, for the
+    static coder, count()'s second rescale (cpprcoder.h:561-570)."""
+    import test_oracle_golden
+    adaptive, static = test_oracle_golden.long_inputs()
+    for label, g in golden["long"]["adaptive"].items():
+        v = adaptive[label]()
+        st, rq, comp = ctx.stream_encode(v)
+        assert (st, rq, len(comp)) == (0, 0, g["size"]), label
+        assert hashlib.sha256(comp).hexdigest() == g["sha256"], label
+        st, rq, back = ctx.stream_decode(comp, len(v))
+        assert (st, rq) == (0, 0) and back == v.tobytes(), label
+    for label, g in golden["long"]["static"].items():
+        v = static[label]()
+        st, rq, comp = ctx.stream_encode(v, coder=1)
+        assert st == 0 and len(comp) == g["size"] and hashlib.sha256(comp).hexdigest() == g["sha256"], label
+        st, rq, back = ctx.stream_decode(comp, len(v), coder=1)
+        assert st == 0 and back == v.tobytes(), label
+    # a long stream into a sink that fills: {Pending, remaining} as cpprcoder.h:708-711
+    v = adaptive["uniform(2MiB+77,3)"]()
+    st, rq, out = ctx.stream_encode(v, sink_capacity=1 << 20)
+    assert st == 1 and 0 < rq < len(v) and len(out) == 1 << 20
+
+
+def test_stream_encode_respects_dst_cap(ctx, oracle):
+    """include/rcx.h: dst holds dst_cap bytes; a result that does not fit is reported, never written.  (Context.stream_encode
+    hands over exactly the documented size and checks canary bytes behind it on every call of this suite.)"""
+    from cpprcoder_amd import rcx
+    data = workloads.zipf(5000, 3)
+    (st0, _), ref, size = oracle.adaptive_encode(data)
+    for cap in (size - 20, size - 4, size, size + 100):  # sinks around "everything fits through writeByte"
+        cap16 = (cap + 15) & ~15  # what MemoryStream(cap).capacity() is (cpprcoder.h:975)
+        st, rq, out = ctx.stream_encode(data, sink_capacity=cap16)
+        (rst, rrq), rout, rsize = oracle.adaptive_encode(data, sink_capacity=cap)
+        assert (st, rq, len(out)) == (rst, rrq, rsize) and out[: len(rout)] == rout
+    st, rq, out = ctx.stream_encode(data, sink_capacity=size, dst_cap=size - 1)
+    assert st == rcx.E_CAPACITY and out == b""
+    st, rq, out = ctx.stream_encode(data, sink_capacity=64, dst_cap=63)  # the pending path copies 64 bytes
+    assert st == rcx.E_CAPACITY
+    st, rq, out = ctx.stream_encode(data, sink_capacity=64, dst_cap=64)
+    assert st == rcx.PENDING and len(out) == 64 and out == ref[:64]
+    st, rq, out = ctx.stream_encode(data, coder=1, dst_cap=600)
+    assert st == rcx.E_CAPACITY
+
+
+def test_static_histogram_past_65535_symbols(ctx, oracle):
+    """count() (cpprcoder.h:543-571) in blocks longer than 65535 symbols: the calm case (no count can reach 0xFFFF:
+    all three waves count with atomics) and the order-dependent 16-bit squeeze (:549-555) in the middle of a block."""
+    block = 262144
+    calm = workloads.uniform(block * 6, 31)
+    text = workloads.canterbury_tiled(block * 5 + 1000)
+    squeeze = np.concatenate([workloads.runs(block * 3, 5), np.full(block, 7, np.uint8),
+                              np.concatenate([np.full(70000, 1, np.uint8), workloads.zipf(block - 70000 - 65000, 3), np.full(65000, 1, np.uint8)])])
+    for data in (calm, text, squeeze):
+        slots, sizes = oracle.encode_blocks(data, block, coder=1, threads=8)
+        payload, offsets, _ = gpu_encode(ctx, data, block, coder=1)
+        assert_same_blocks(payload, offsets, slots, sizes)
+        back, st, _ = gpu_decode(ctx, payload, offsets, len(data), block, coder=1)
+        assert st == 0 and np.array_equal(back, data)

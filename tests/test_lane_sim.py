@@ -33,6 +33,8 @@ def sim():
     L.sim_stream_decode_track.restype = C.c_uint32
     L.sim_stream_decode_track.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
     L.sim_counters.restype, L.sim_counters.argtypes = None, [C.c_void_p, C.c_int]
+    L.sim_stream_encode_long.restype, L.sim_stream_encode_long.argtypes = C.c_uint32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
+    L.sim_stream_decode_long.restype, L.sim_stream_decode_long.argtypes = C.c_uint32, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
     return L
 
 
@@ -43,8 +45,11 @@ def counters(sim, reset=True):
 
 
 def test_divisor_table_is_exact(sim):
-    # every total a block of up to RCX_MAX_BLOCK symbols can see, probed at the edges of each quotient
+    # every total a block of up to RCX_MAX_BLOCK = 2^24 - 256 symbols can see, probed at the edges of each quotient
     assert sim.sim_check_divtab(256, 256 + (1 << 20) + 128) == 0
+    for first in range(1 << 21, 1 << 24, 1 << 21):  # and samples of the rest up to 2^24 (+ the table's padding)
+        assert sim.sim_check_divtab(first - 2000, first + 2000) == 0
+    assert sim.sim_check_divtab((1 << 24) - 70000, (1 << 24) + 300) == 0
 
 
 def roundtrip(sim, oracle, data, block, lane):
@@ -133,3 +138,22 @@ def test_stream_decode_tracking(sim, oracle, golden):
         (st, rq), ref_out, _ = oracle.adaptive_decode(junk, 64)
         assert st == 0 and short_at == 0xFFFFFFFF and bytes(out) == ref_out == bytes.fromhex(pin["out_hex"])
     assert counters(sim)[2] > 0  # the off-table path was taken
+
+
+def test_long_stream_through_the_halving(sim, oracle):
+    # cpprcoder.h:1138-1176: past 2^24 - 256 symbols the table is halved; the lane's step_long path must produce the
+    # oracle's bytes (the oracle's model is pinned through the halving by the reference's model probes)
+    cases = [workloads.uniform((1 << 24) - 256 + 5000, 11),
+             np.minimum(workloads.zipf((1 << 24) + 70000, 5), 3).astype(np.uint8),
+             workloads.zipf(300000, 8)]  # the long path on a short stream
+    for data in cases:
+        n = len(data)
+        (st, rq), ref_bytes, ref_size = oracle.adaptive_encode(data)
+        assert st == 0
+        slot = np.zeros(oracle.default_capacity(n) + 64, np.uint8)
+        size = sim.sim_stream_encode_long(data.ctypes.data, n, slot.ctypes.data, len(slot) - 32)
+        assert size == ref_size and bytes(slot[:size]) == ref_bytes
+        out = np.zeros(n, np.uint8)
+        comp = np.frombuffer(ref_bytes, np.uint8).copy()
+        assert sim.sim_stream_decode_long(comp.ctypes.data, len(comp), n, out.ctypes.data) == 0xFFFFFFFF
+        assert np.array_equal(out, data)

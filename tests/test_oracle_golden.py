@@ -186,3 +186,43 @@ def test_against_reference_build(oracle, reference):
         so, zo = oracle.encode_blocks(data, block, threads=4)
         sr, zr = reference.encode_blocks(data, block, threads=4)
         assert np.array_equal(zo, zr) and np.array_equal(so, sr)
+
+
+def long_inputs():
+    """The recipes of tests/golden/make_golden_long.py (label -> bytes)."""
+    no_halving = (1 << 24) - 256
+    adaptive = {
+        "uniform(2MiB+77,3)": lambda: workloads.uniform((2 << 20) + 77, 3),
+        "zipf(NO_HALVING,4)": lambda: workloads.zipf(no_halving, 4),
+        "uniform(NO_HALVING+5000,11)": lambda: workloads.uniform(no_halving + 5000, 11),
+        "min(zipf(2^24+70000,5),3)": lambda: np.minimum(workloads.zipf((1 << 24) + 70000, 5), 3).astype(np.uint8),
+    }
+    static = {
+        "zipf(2^24+1000,6)": lambda: workloads.zipf((1 << 24) + 1000, 6),
+        "runs(3MiB,2)": lambda: workloads.runs(3 << 20, 2),
+    }
+    return adaptive, static
+
+
+def test_long_streams_and_big_blocks(oracle, golden):
+    # past 1 MiB, up to and through the halving at total = 2^24 (cpprcoder.h:1138-1176) and the static coder's
+    # second rescale (cpprcoder.h:561-570): the restatement against the reference's own output
+    adaptive, static = long_inputs()
+    for label, g in golden["long"]["adaptive"].items():
+        v = adaptive[label]()
+        assert sha(v) == g["input_sha256"]
+        (st, rq), comp, size = oracle.adaptive_encode(v)
+        assert (st, rq, size, sha(comp)) == (0, 0, g["size"], g["sha256"]), label
+        (st, rq), back, _ = oracle.adaptive_decode(comp, len(v))
+        assert (st, rq) == (0, 0) and back == v.tobytes()
+    for label, g in golden["long"]["static"].items():
+        v = static[label]()
+        assert sha(v) == g["input_sha256"]
+        ok, comp, size = oracle.static_encode(v)
+        assert ok and (size, sha(comp)) == (g["size"], g["sha256"]), label
+    for t in golden["long"]["blocks"]:
+        data = workloads.by_name(t["workload"], t["n"], t["seed"])
+        assert sha(data) == t["input_sha256"]
+        slots, sizes = oracle.encode_blocks(data, t["block"], coder=0 if t["coder"] == "adaptive" else 1, threads=4)
+        assert [int(x) for x in sizes] == t["sizes"]
+        assert ["%016x" % oracle_lib.fnv1a64(slots[b, : int(sizes[b])]) for b in range(len(sizes))] == t["fnv1a64"]
