@@ -6,9 +6,11 @@
 
 One "step" = one pass of the hot path over one batch of synthetic input that is already
 resident in HBM: encode 1 GiB (per GPU) of 64 KiB blocks into the compacted stream
-(encode kernel + size prefix + scatter), then decode it back (BASELINE.json configs[1]).
-With N > 1 every rank codes its own 1 GiB shard (weak scaling) and the compressed segments
-are concatenated on every rank (allgatherv over RCCL) while the decode runs.
+(encode kernel + size prefix + scatter), then decode it back.  The default workload at N = 1 is
+BASELINE.json configs[1] (mt19937(12345) uniform bytes); with N > 1 it is configs[3]'s (Zipf bytes,
+mt19937(12345 + rank) per shard): every rank codes its own 1 GiB shard (weak scaling) and the compressed
+segments and block tables are concatenated on every rank (rcx_allgatherv_segments: RCCL point to point
+over xGMI) while the decode runs.  `config.workload` says which BASELINE.json config the line is.
 
 Prints ONE JSON line on rank 0.  `value` = uncompressed MB/s through the whole round trip
 (all ranks' bytes / max-over-ranks time).  `roofline` prices the dominant kernel against the
@@ -34,53 +36,63 @@ BLOCK = 65536
 
 
 def make_workload(name: str, n: int, seed: int, device):
-    """Synthetic bytes of the named shape, generated on the host (seeded mt19937) and moved to HBM."""
+    """Synthetic bytes of the named shape (SURVEY.md section 8(d)), generated on the host from std::mt19937(seed)
+    and moved to HBM.  The CPU baseline below draws the first bytes of the very same stream."""
     import torch
     from cpprcoder_amd import workloads
     t0 = time.time()
-    if name == "uniform" and n >= (1 << 28):
-        # 1 GiB of mt19937 output takes ~15 s per rank; draw 64 MiB and extend it with a keyed
-        # xor-shuffle so every 64 KiB block is still incompressible and distinct.
-        base = torch.from_numpy(workloads.uniform(1 << 26, seed)).to(device)
-        g = torch.Generator(device=device)
-        g.manual_seed(seed)
-        data = torch.randint(0, 256, (n,), dtype=torch.uint8, device=device, generator=g)
-        reps = n // base.numel()
-        data.view(reps, -1).bitwise_xor_(base.unsqueeze(0))
-    else:
-        data = torch.from_numpy(workloads.by_name(name, n, seed)).to(device)
-    return data, time.time() - t0
+    host = workloads.by_name(name, n, seed)
+    data = torch.from_numpy(host).to(device)
+    return data, host, time.time() - t0
 
 
-def cpu_baseline(name: str, seed: int, sample_bytes: int):
-    """The reference's CPU coder on a bounded sample of the same workload, all host cores."""
+def baseline_config(name: str, n: int, block: int, world: int) -> str:
+    """Which BASELINE.json config this run is (0-based index into `configs`), in BASELINE.json's own words."""
+    try:
+        configs = json.load(open(os.path.join(ROOT, "BASELINE.json")))["configs"]
+    except Exception:
+        return "BASELINE.json not readable"
+    gib = n == (1 << 30)
+    if name == "uniform" and gib and block == BLOCK and world == 1:
+        return "configs[1]: " + configs[1]
+    if name == "canterbury" and gib and block == BLOCK and world == 1:
+        return "configs[2]: " + configs[2]
+    if name == "zipf" and gib and block == BLOCK and world == 8:
+        return "configs[3]: " + configs[3]
+    if name == "zipf" and gib and block == BLOCK:
+        return f"configs[3] at {world} of its 8 GPUs (1 GiB Zipf shard per GPU, weak scaling): " + configs[3]
+    if gib and world == 1 and block != BLOCK:
+        return "configs[4] (one point of the block-size sweep): " + configs[4]
+    return "none of BASELINE.json's configs (a variation for diagnosis)"
+
+
+def cpu_baseline(data: np.ndarray, block: int):
+    """The reference's CPU coder on a bounded sample of the same bytes the GPU coded, all host cores."""
     import oracle_lib
-    from cpprcoder_amd import workloads
     oracle_lib.build_oracle()
     chk = oracle_lib.reference() or oracle_lib.oracle()
     cores = os.cpu_count() or 1
-    data = workloads.by_name(name, sample_bytes, seed)
     t0 = time.time()
-    slots, sizes = chk.encode_blocks(data, BLOCK, threads=cores)
+    slots, sizes = chk.encode_blocks(data, block, threads=cores)
     t1 = time.time()
-    back, ok = chk.decode_blocks(slots, sizes, BLOCK, len(data), threads=cores)
+    back, ok = chk.decode_blocks(slots, sizes, block, len(data), threads=cores)
     t2 = time.time()
     assert ok and np.array_equal(back, data)
     one = data[: min(len(data), 8 << 20)]
     s0 = time.time()
-    s_slots, s_sizes = chk.encode_blocks(one, BLOCK, threads=1)
+    s_slots, s_sizes = chk.encode_blocks(one, block, threads=1)
     s1 = time.time()
-    chk.decode_blocks(s_slots, s_sizes, BLOCK, len(one), threads=1)
+    chk.decode_blocks(s_slots, s_sizes, block, len(one), threads=1)
     s2 = time.time()
     mb = len(data) / 1e6
     return {
         "value": round(mb / (t2 - t0), 2), "unit": "MB/s", "cores": cores, "kind": chk.kind,
-        "sample": f"first {len(data) >> 20} MiB of the same workload, {BLOCK >> 10} KiB blocks, encode+decode round trip, "
+        "sample": f"the first {len(data) >> 20} MiB of the very bytes the GPU coded, {block >> 10} KiB blocks, encode+decode round trip, "
                   f"{cores} threads over a block range split (fresh coder per block, as test/main.cpp:325-344)",
         "encode_MBps": round(mb / (t1 - t0), 2), "decode_MBps": round(mb / (t2 - t1), 2),
         "one_thread_encode_MBps": round(len(one) / 1e6 / (s1 - s0), 2), "one_thread_decode_MBps": round(len(one) / 1e6 / (s2 - s1), 2),
         "ratio": round(float(sizes.astype(np.uint64).sum()) / len(data), 6),
-    }
+    }, sizes
 
 
 # The contract is ONE line on stdout.  RCCL prints a version banner to stdout when a communicator is created
@@ -102,7 +114,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="uniform", choices=["uniform", "zipf", "canterbury", "runs"])
+    ap.add_argument("--workload", default=None, choices=["uniform", "zipf", "canterbury", "runs"],
+                    help="default: uniform on one GPU (BASELINE.json configs[1]), zipf on several (configs[3])")
     ap.add_argument("--bytes", type=int, default=1 << 30, help="uncompressed bytes per GPU")
     ap.add_argument("--block", type=int, default=BLOCK)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -133,26 +146,29 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    if args.workload is None:
+        args.workload = "uniform" if world == 1 else "zipf"
     n, block = args.bytes, args.block
     nblocks = rcx.block_count(n, block)
     seed = 12345 + rank  # mt19937(12345 + rank) per shard
-    src, gen_s = make_workload(args.workload, n, seed, device)
+    src, host_src, gen_s = make_workload(args.workload, n, seed, device)
     ctx = rcx.Context(local)
     ctx.reserve(n, block)
     bound = rcx.encode_bound(n, block)
-    # Two compressed buffers: with the exchange on, step i+1 encodes into the other one while the allgatherv of
+    # Two compressed buffers: with the exchange on, step i+1 encodes into the other one while the exchange of
     # step i is still reading this one (the exchange of a step overlaps its own decode AND the next step's encode).
-    nbuf = 2 if (world > 1 or args.exchange) else 1
-    comps = [torch.empty(bound + 256, dtype=torch.uint8, device=device) for _ in range(nbuf)]  # +256: segments are padded to 256 B
+    nbuf = 2 if exchange else 1
+    comps = [torch.empty(bound, dtype=torch.uint8, device=device) for _ in range(nbuf)]
     offss = [torch.zeros(nblocks + 1, dtype=torch.int64, device=device) for _ in range(nbuf)]
     out = torch.empty(n, dtype=torch.uint8, device=device)
-    concat = torch.empty((bound + 256) * world, dtype=torch.uint8, device=device) if exchange else None
-    staging = torch.empty((bound + 256) * world, dtype=torch.uint8, device=device) if exchange else None
+    concat = torch.empty(bound * world, dtype=torch.uint8, device=device) if exchange else None
+    table = torch.zeros(nblocks * world + 1, dtype=torch.int64, device=device) if exchange else None
+    comm = parallel.Comm.from_process_group(local) if exchange else None  # rcx_comm over RCCL (include/rcx.h)
     side = torch.cuda.Stream(device=device) if exchange else None
     main_stream = torch.cuda.current_stream()
     gather_ms = []
     released = [None] * nbuf  # event: the exchange that read buffer b has finished
-    state = {"i": 0, "table": None, "last": 0}
+    state = {"i": 0, "bases": None, "last": 0}
 
     def step():
         b = state["i"] % nbuf
@@ -162,24 +178,20 @@ def main() -> None:
         if released[b] is not None:
             main_stream.wait_event(released[b])
         ctx.encode_blocks_device(src, block, comp, offs)
-        if not exchange:
-            # the decoder takes the block table from HBM: no host round trip inside the step
-            ctx.decode_blocks_device(comp, bound, offs, n, block, out)
-            return
-        total = int(offs[-1])  # the exchange needs the segment size on the host
-        side.wait_stream(main_stream)  # (exchanges also queue behind each other on the side stream)
-        ctx.decode_blocks_device(comp, total, offs, n, block, out)   # own shard, overlaps the exchange
-        with torch.cuda.stream(side):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            bases, sizes, works = parallel.allgatherv_segments(comp, total, concat, staging=staging)
-            table = parallel.allgather_offsets(offs, bases)
-            for w in works:
-                w.wait()
-            e1.record()
-            gather_ms.append((e0, e1))
-            state["table"] = table
-            released[b] = e1
+        if exchange:
+            side.wait_stream(main_stream)  # the exchange starts when the encode is done (and queues behind the previous one)
+        # the decoder takes the block table from HBM: no host round trip between encode and decode
+        ctx.decode_blocks_device(comp, bound, offs, n, block, out)
+        if exchange:
+            # one call: sizes all-gather (its one host sync waits for the encode only), then every segment and table
+            # part point to point straight into place -- while the decode above runs on the main stream
+            with torch.cuda.stream(side):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                state["bases"] = comm.allgatherv(comp, offs, concat, table, stream=side)
+                e1.record()
+                gather_ms.append((e0, e1))
+                released[b] = e1
 
     def fence():
         torch.cuda.synchronize()
@@ -210,16 +222,20 @@ def main() -> None:
     total = int(offs[-1])
     ratio = total / n
 
+    timing_local = {k: v["ms"] / max(1, v["launches"]) for k, v in timing.items()}
+    codec_ms = sum(timing_local.values())
     if exchange:
-        t = torch.tensor([wall], dtype=torch.float64, device=device)
+        t = torch.tensor([wall, codec_ms], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t[0])
+        wall, codec_ms = float(t[0]), float(t[1])
         ok = torch.tensor([1 if roundtrip_ok else 0], device=device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         roundtrip_ok = bool(int(ok[0]))
-        # the concatenated stream must hold this rank's segment at its base
-        bases = [int(x) for x in (state["table"][::nblocks][:world]).cpu()]
-        roundtrip_ok = roundtrip_ok and bool(torch.equal(concat[bases[rank]: bases[rank] + total], comp[:total]))
+        # the concatenated stream must hold this rank's segment at its base, and the global table its offsets
+        seg_base, block_base = state["bases"]
+        roundtrip_ok = roundtrip_ok and bool(torch.equal(concat[seg_base[rank]: seg_base[rank] + total], comp[:total]))
+        roundtrip_ok = roundtrip_ok and bool(torch.equal(table[block_base[rank]: block_base[rank] + nblocks] - seg_base[rank], offs[:nblocks]))
+        roundtrip_ok = roundtrip_ok and int(table[block_base[-1]]) == seg_base[-1]
 
     if rank == 0:
         ms_step = wall * 1e3 / args.steps
@@ -233,11 +249,20 @@ def main() -> None:
         dom, dom_ms = (dec_name, dec_ms) if dec_ms >= enc_ms else (enc_name, enc_ms)
         algo_bytes = (1.0 + ratio) * n  # 1 read + r write per input byte (or r read + 1 write)
         achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch of the dominant kernel from the PMC passes (separate rocprofv3 --pmc runs cannot happen
+        # inside this process): replayed from profiles/pmc_traffic.json, and only if that file was recorded on the
+        # workload this run is on -- otherwise null.
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc))
+                cfg = rec.get("_config", {})
+                if (cfg.get("workload"), cfg.get("bytes"), cfg.get("block")) == (args.workload, n, block):
+                    traffic = rec.get(dom, {}).get("hbm_bytes_per_launch")
+                    traffic_source = f"profiles/pmc_traffic.json ({cfg.get('recorded', 'an earlier rocprofv3 --pmc run')} on this workload), not measured by this run"
+                else:
+                    traffic_source = "none: profiles/pmc_traffic.json was recorded on another workload"
             except Exception:
                 traffic = None
         line = {
@@ -246,35 +271,47 @@ def main() -> None:
             "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"{n >> 20} MiB synthetic {args.workload} bytes per GPU, {block >> 10} KiB blocks, "
-                                   f"encode+decode round trip resident in HBM (BASELINE.json configs[1])",
+            "config": {"workload": f"{n >> 20} MiB synthetic {args.workload} bytes per GPU (std::mt19937({seed if world == 1 else '12345 + rank'})), "
+                                   f"{block >> 10} KiB blocks, encode+decode round trip resident in HBM",
+                       "baseline_config": baseline_config(args.workload, n, block, world),
                        "bytes_per_gpu": n, "block": block, "blocks_per_gpu": nblocks,
                        "parallelism": f"blocks sharded over {world} GPU(s), one process per GPU"
-                                      + ("; allgatherv of the compressed segments overlapped with the decode and with the next step's encode" if exchange else "")},
+                                      + ("; rcx_allgatherv_segments (RCCL send/recv straight into place) overlapped with the decode and with the next step's encode" if exchange else "")},
             "roundtrip_ok": roundtrip_ok, "ratio": round(ratio, 6),
             "encode_MBps": round(n / 1e6 / ((enc_ms + scan_ms + scat_ms) * 1e-3), 1),
             "decode_MBps": round(n / 1e6 / (dec_ms * 1e-3), 1),
             "kernel_ms": {"encode": round(enc_ms, 4), "scan": round(scan_ms, 4), "scatter": round(scat_ms, 4), "decode": round(dec_ms, 4)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "note": "per-block coding is a serial chain per symbol; the ceiling that actually binds is "
                                  "blocks_in_flight x clock / cycles_per_symbol (DESIGN.md), not HBM"},
             "workload_gen_s": round(gen_s, 2),
         }
         if exchange and gather_ms:
-            line["allgatherv_ms"] = round(sum(a.elapsed_time(b) for a, b in gather_ms) / len(gather_ms), 3)
+            # codec-only and codec+exchange separately.  `value` above is the whole step (the
+            # exchange overlaps the decode and the next encode); codec-only is the sum of the kernel times (max over ranks).
+            ag_ms = sum(a.elapsed_time(b) for a, b in gather_ms) / len(gather_ms)
+            line["allgatherv_ms"] = round(ag_ms, 3)
+            line["codec_only_MBps"] = round(world * n / 1e6 / (codec_ms * 1e-3), 1)
+            line["codec_plus_allgatherv_MBps"] = line["value"]
+            line["allgatherv_in_GBps_per_gpu"] = round((world - 1) * total / 1e9 / (ag_ms * 1e-3), 2) if world > 1 else 0.0
         if world == 1 and not args.no_cpu_baseline:
             try:
-                cb = cpu_baseline(args.workload, seed, min(n, args.cpu_sample_mib << 20))
+                sample = host_src[: min(n, args.cpu_sample_mib << 20) // block * block or n]
+                cb, cpu_sizes = cpu_baseline(sample, block)
                 line["cpu_baseline"] = cb
                 line["gpu_over_cpu"] = round(line["value"] / cb["value"], 1)
+                # same bytes on both sides: the GPU's per-block stream sizes must be the CPU coder's
+                gpu_sizes = (offs[1: len(cpu_sizes) + 1] - offs[: len(cpu_sizes)]).cpu().numpy()
+                line["cpu_baseline"]["block_sizes_equal_gpu"] = bool(np.array_equal(gpu_sizes, cpu_sizes.astype(np.int64)))
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         os.write(_REAL_STDOUT, (json.dumps(line) + "\n").encode())
 
     ctx.close()
     if exchange:
+        comm.close()
         dist.destroy_process_group()
 
 

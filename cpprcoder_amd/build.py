@@ -11,7 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librcx.so")
-SOURCES = ["rcx_api.hip"]
+SOURCES = ["rcx_api.hip", "rcx_comm.hip"]
 HEADERS = ["rcx_lane.hpp", "rcx_divtab.hpp", "rcx_kernels.hpp", "rcx_oct.hpp", "rcx_static.hpp", os.path.join("..", "..", "include", "rcx.h")]
 
 
@@ -34,7 +34,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-L/opt/rocm/lib", "-lrccl"]  # rcx_comm.hip: RCCL
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or proc.returncode != 0:
         print(" ".join(cmd))

@@ -213,6 +213,7 @@ const char* rcx_status_string(int status)
     case RCX_E_CORRUPT: return "corrupt or truncated block stream";
     case RCX_E_HIP: return "HIP runtime error";
     case RCX_E_NOMEM: return "out of memory";
+    case RCX_E_COMM: return "RCCL error";
     default: return "unknown status";
     }
 }
@@ -361,20 +362,21 @@ int rcx_encode_blocks_device(rcx_ctx* c, int coder, const void* d_src, uint64_t 
                                nblocks, c->slots, slot, c->sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr),
                                static_cast<const u32*>(nullptr));
         }
-    }
-    if (static3) { // the same for the static coder
-        const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
-        hipLaunchKernelGGL(rcx_enc_static_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block, nblocks,
-                           c->slots, slot, c->sizes, c->status, static_cast<const u32*>(c->redo));
-    }
-    if (coder == RCX_CODER_ADAPTIVE && c->enc_variant == 3) {
-        // Blocks in which a carry ran through more output bytes than the five-wave kernel keeps in LDS were
-        // marked, not finished: the one-wave kernel encodes them again.  Nothing is marked on ordinary data
-        // and every wave of this launch returns at once.
-        const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
-        hipLaunchKernelGGL(rcx_enc_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block,
-                           nblocks, c->slots, slot, c->sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr),
-                           static_cast<const u32*>(c->redo));
+        // (the second passes are part of the encode time: on adversarial data they are not free)
+        if (static3) { // the same for the static coder
+            const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
+            hipLaunchKernelGGL(rcx_enc_static_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block, nblocks,
+                               c->slots, slot, c->sizes, c->status, static_cast<const u32*>(c->redo));
+        }
+        if (coder == RCX_CODER_ADAPTIVE && c->enc_variant == 3) {
+            // Blocks in which a carry ran through more output bytes than the five-wave kernel keeps in LDS were
+            // marked, not finished: the one-wave kernel encodes them again.  Nothing is marked on ordinary data
+            // and every wave of this launch returns at once.
+            const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
+            hipLaunchKernelGGL(rcx_enc_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block,
+                               nblocks, c->slots, slot, c->sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr),
+                               static_cast<const u32*>(c->redo));
+        }
     }
     {
         Timed t(c, s, RCX_T_SCAN);
@@ -449,20 +451,20 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
                                nblocks, block, n, static_cast<u8*>(d_dst), c->divtab, c->status, static_cast<u32*>(nullptr),
                                static_cast<const u32*>(nullptr));
         }
-    }
-    if (quad) {
-        // Blocks whose stream asked for a symbol past the table (corrupt input) were marked, not decoded, by
-        // the quad kernel: the one-lane kernel, which has the reference's fall-through for that case, decodes
-        // them again.  On valid input nothing is marked and every wave of this launch returns at once.
-        const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
-        hipLaunchKernelGGL(rcx_dec_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets,
-                           nblocks, block, n, static_cast<u8*>(d_dst), c->divtab, c->status, static_cast<u32*>(nullptr),
-                           static_cast<const u32*>(c->redo));
-    }
-    if (squad) { // the same for the static coder: a target past the table or a symbol of count 0
-        const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
-        hipLaunchKernelGGL(rcx_dec_static_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks,
-                           block, n, static_cast<u8*>(d_dst), c->status, static_cast<u32*>(nullptr), static_cast<const u32*>(c->redo));
+        if (quad) {
+            // Blocks whose stream asked for a symbol past the table (corrupt input) were marked, not decoded, by
+            // the quad kernel: the one-lane kernel, which has the reference's fall-through for that case, decodes
+            // them again.  On valid input nothing is marked and every wave of this launch returns at once.
+            const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
+            hipLaunchKernelGGL(rcx_dec_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets,
+                               nblocks, block, n, static_cast<u8*>(d_dst), c->divtab, c->status, static_cast<u32*>(nullptr),
+                               static_cast<const u32*>(c->redo));
+        }
+        if (squad) { // the same for the static coder: a target past the table or a symbol of count 0
+            const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
+            hipLaunchKernelGGL(rcx_dec_static_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks,
+                               block, n, static_cast<u8*>(d_dst), c->status, static_cast<u32*>(nullptr), static_cast<const u32*>(c->redo));
+        }
     }
     return hipGetLastError() == hipSuccess ? RCX_OK : RCX_E_HIP;
 }

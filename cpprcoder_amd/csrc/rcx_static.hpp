@@ -212,7 +212,9 @@ __global__ __launch_bounds__(64) void rcx_enc_static_k(const u8* __restrict__ sr
 #define RCX_ST3_THREADS 192
 #define RCX_ST3_LDS_DW (RCX_STATIC_LDS_DW + 4 * RCX_MC_RING_U4 + RCX_MC5_RING2_DW + RCX_LANES + RCX_MC5_OUT_DW)
 
-template <bool FULL>
+// WIDE: full 32-bit multiplies.  With a total below 256, t = range / total can exceed 24 bits; from 256 on it cannot,
+// and cum and count never do (total <= 2^24), so the 24-bit multiplies of the adaptive coder are exact.
+template <bool FULL, bool WIDE>
 __device__ __forceinline__ void rcx_static3_pipeline(u32 wave, u32 lane, u32 len, u32 nchunks, const u8* in, const StaticTable& tab,
                                                      U4* ring, u32* ring2, EncLane& enc, const DivEntry& kdiv, StagedWriter& wr,
                                                      u32* out_pos, u32& drained, u8* payload, u32 cap, bool live)
@@ -233,7 +235,7 @@ __device__ __forceinline__ void rcx_static3_pipeline(u32 wave, u32 lane, u32 len
                     const U4 e = e_next;
                     if (s + 1 < RCX_MC_CHUNK) e_next = rs[(s + 1) * RCX_LANES];
                     u32 rec = 0;
-                    if (FULL || i0 + s < len) rec = enc.template arith<true>(e.x, e.w, kdiv); // cpprcoder.h:402-408
+                    if (FULL || i0 + s < len) rec = enc.template arith<WIDE>(e.x, e.w, kdiv); // cpprcoder.h:402-408
                     ws2[s * RCX_LANES] = rec;
                 }
             }
@@ -415,8 +417,10 @@ __global__ __launch_bounds__(RCX_ST3_THREADS) void rcx_enc_static3_k(const u8* _
 
     u8* payload = wave_slots + (u64)lane * slot + RCX_STATIC_HEADER;
     const u32 cap = (((u32)slot - 4) & ~3u) - (RCX_STATIC_HEADER - 4);
-    if (full) rcx_static3_pipeline<true>(wave, lane, len, nchunks, in, tab, ring, ring2, enc, k, wr, out_pos, drained, payload, cap, live);
-    else rcx_static3_pipeline<false>(wave, lane, len, nchunks, in, tab, ring, ring2, enc, k, wr, out_pos, drained, payload, cap, live);
+    const bool narrow = __all(total >= 256u); // every wave sees the same table
+    if (full && narrow) rcx_static3_pipeline<true, false>(wave, lane, len, nchunks, in, tab, ring, ring2, enc, k, wr, out_pos, drained, payload, cap, live);
+    else if (full) rcx_static3_pipeline<true, true>(wave, lane, len, nchunks, in, tab, ring, ring2, enc, k, wr, out_pos, drained, payload, cap, live);
+    else rcx_static3_pipeline<false, true>(wave, lane, len, nchunks, in, tab, ring, ring2, enc, k, wr, out_pos, drained, payload, cap, live);
 
     if (wave == 0) final_low[lane] = enc.low;
     if (wave == 2) {

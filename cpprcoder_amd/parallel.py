@@ -1,77 +1,129 @@
-"""Multi-GPU host side: one process per GPU, blocks sharded by rank, and the one real exchange
-step of the path -- concatenating the per-rank compressed segments on every rank (allgatherv).
+"""Multi-GPU host side: one process per GPU, blocks sharded by rank, and the one real exchange step of the path --
+putting the per-rank compressed segments and their block tables together on every rank ("allgatherv").
 
-The reference has no multi-device code at all; blocks are independent, so coding
-needs no collective.  RCCL has no native allgatherv; it is done here as one size all-gather, one fixed-size
-all-gather of the segments padded to the largest, and a local compaction (or, optionally, one broadcast per
-root).  The same code runs on gloo/CPU tensors, which is how the tests cover it.
+The reference has no multi-device code at all; blocks are independent, so coding needs no
+collective.  The exchange itself lives in the C ABI (include/rcx.h: rcx_comm_*, rcx_allgatherv_segments -- RCCL
+point-to-point sends and receives straight into place); `Comm` below is its binding.  `allgatherv_p2p` is the same
+exchange written over torch.distributed point-to-point calls: it runs on gloo/CPU tensors, which is how the tests
+cover the offset arithmetic without a GPU; both use the same plan function of the library (rcx_exchange_plan).
 """
 from __future__ import annotations
 
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import rcx
+
 
 def shard_blocks(nblocks: int, world: int, rank: int) -> tuple[int, int]:
-    """Contiguous block range [first, last) of `rank`."""
+    """Contiguous block range [first, last) of `rank`; ranks may get unequal counts."""
     return nblocks * rank // world, nblocks * (rank + 1) // world
 
 
-def allgatherv_segments(segment: torch.Tensor, seg_bytes: int, concat: torch.Tensor, group=None, staging: torch.Tensor | None = None,
-                        method: str = "allgather"):
-    """Concatenate every rank's first `seg_bytes` bytes of `segment` into `concat` on all ranks.
+def exchange_plan(seg_bytes, nblocks) -> tuple[list[int], list[int]]:
+    """Where every rank's bytes and blocks start in the concatenation (rcx_exchange_plan; pure, no GPU)."""
+    n = len(seg_bytes)
+    seg = (C.c_uint64 * n)(*[int(x) for x in seg_bytes])
+    blk = (C.c_uint64 * n)(*[int(x) for x in nblocks])
+    seg_base, block_base = (C.c_uint64 * (n + 1))(), (C.c_uint64 * (n + 1))()
+    st = rcx.lib().rcx_exchange_plan(seg, blk, n, seg_base, block_base)
+    if st != rcx.OK:
+        raise rcx.RcxError(st, "rcx_exchange_plan")
+    return list(seg_base), list(block_base)
 
-    RCCL has no allgatherv.  method="allgather" (default): one size all-gather, then ONE fixed-size
-    all_gather_into_tensor of segments padded to the largest one (the collective RCCL is tuned for: per-block
-    streams make the segments of equal-sized shards differ by well under 1 %), then a local compaction of the
-    padded rows into `concat`.  method="broadcast": one broadcast per root straight into `concat` (no padding,
-    no staging, but N separate collectives).
 
-    Returns (bases, sizes, works): python lists of the per-rank base offset / size in `concat`, and async work
-    handles to wait on before reading `concat` (empty for method="allgather", which completes on the current
-    stream in order).
-    """
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    mine = torch.tensor([seg_bytes], dtype=torch.int64, device=segment.device)
-    every = torch.zeros(world, dtype=torch.int64, device=segment.device)
+def allgatherv_p2p(segment: torch.Tensor, offsets: torch.Tensor, concat: torch.Tensor, table: torch.Tensor | None, group=None):
+    """The exchange of rcx_allgatherv_segments over torch.distributed point-to-point calls (any backend).
+
+    segment: this rank's compacted streams; offsets: its nblocks+1 table (offsets[-1] = segment bytes); concat receives
+    the segments back to back; table (optional) the table of the concatenation.  Returns (seg_base, block_base).
+    Every rank raises together if a buffer is too small (the plan is the same everywhere)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    nblocks = offsets.numel() - 1
+    mine = torch.stack([offsets[-1].to(torch.int64), torch.tensor(nblocks, dtype=torch.int64, device=offsets.device)])
+    every = torch.zeros(2 * world, dtype=torch.int64, device=offsets.device)
     dist.all_gather_into_tensor(every, mine, group=group)
-    sizes = [int(x) for x in every.cpu()]
-    bases = [0] * world
-    for r in range(1, world):
-        bases[r] = bases[r - 1] + sizes[r - 1]
-    if bases[-1] + sizes[-1] > concat.numel():
-        raise ValueError("concat buffer too small for the gathered segments")
-    if method == "broadcast":
-        concat[bases[rank]: bases[rank] + seg_bytes].copy_(segment[:seg_bytes])
-        works = []
-        for r in range(world):
-            if sizes[r] == 0:
-                continue
-            view = concat[bases[r]: bases[r] + sizes[r]]
-            src = dist.get_global_rank(group, r) if group is not None else r
-            works.append(dist.broadcast(view, src=src, group=group, async_op=True))
-        return bases, sizes, works
-    row = (max(sizes) + 255) & ~255  # padded segment length, the same on every rank
-    if row > segment.numel():
-        raise ValueError("segment buffer shorter than the padded segment length")
-    if staging is None or staging.numel() < world * row:
-        staging = torch.empty(world * row, dtype=segment.dtype, device=segment.device)
-    dist.all_gather_into_tensor(staging[: world * row], segment[:row], group=group)
-    for r in range(world):
-        if sizes[r]:
-            concat[bases[r]: bases[r] + sizes[r]].copy_(staging[r * row: r * row + sizes[r]])
-    return bases, sizes, []
+    every = every.cpu().view(world, 2)
+    seg, blk = [int(x) for x in every[:, 0]], [int(x) for x in every[:, 1]]
+    seg_base, block_base = exchange_plan(seg, blk)
+    if seg_base[-1] > concat.numel() or (table is not None and block_base[-1] + 1 > table.numel()):
+        raise ValueError("concat / table too small for the gathered segments")
+    concat[seg_base[rank]: seg_base[rank] + seg[rank]].copy_(segment[: seg[rank]])
+    if table is not None:
+        table[block_base[rank]: block_base[rank] + nblocks].copy_(offsets[:nblocks] + seg_base[rank])
+        if rank == world - 1:
+            table[block_base[-1]] = seg_base[-1]
+    ops = []
+    glob = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    for step in range(1, world):
+        to, frm = (rank + step) % world, (rank - step) % world
+        if seg[rank]:
+            ops.append(dist.P2POp(dist.isend, segment[: seg[rank]], glob(to), group))
+        if seg[frm]:
+            ops.append(dist.P2POp(dist.irecv, concat[seg_base[frm]: seg_base[frm] + seg[frm]], glob(frm), group))
+        if table is not None:
+            mine_n, theirs_n = blk[rank] + (rank == world - 1), blk[frm] + (frm == world - 1)
+            if mine_n:
+                ops.append(dist.P2POp(dist.isend, table[block_base[rank]: block_base[rank] + mine_n], glob(to), group))
+            if theirs_n:
+                ops.append(dist.P2POp(dist.irecv, table[block_base[frm]: block_base[frm] + theirs_n], glob(frm), group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return seg_base, block_base
 
 
-def allgather_offsets(offsets: torch.Tensor, bases: list[int], group=None) -> torch.Tensor:
-    """Global offset table from the per-rank ones (equal block counts per rank): rank r's local
-    offsets shifted by its segment base; the final entry is the total size."""
-    world = dist.get_world_size(group)
-    per = offsets.numel() - 1
-    table = torch.zeros(world * offsets.numel(), dtype=offsets.dtype, device=offsets.device)
-    dist.all_gather_into_tensor(table, offsets.contiguous(), group=group)
-    table = table.view(world, per + 1)
-    shift = torch.tensor(bases, dtype=offsets.dtype, device=offsets.device).unsqueeze(1)
-    shifted = table + shift
-    return torch.cat([shifted[:, :per].reshape(-1), shifted[-1, per:]])
+class Comm:
+    """One rcx_comm: this process's GPU in the node's RCCL communicator (include/rcx.h)."""
+
+    def __init__(self, device: int, unique_id: bytes, nranks: int, rank: int):
+        self._h = C.c_void_p()
+        buf = (C.c_char * rcx.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        st = rcx.lib().rcx_comm_create(device, buf, nranks, rank, C.byref(self._h))
+        if st != rcx.OK:
+            raise rcx.RcxError(st, "rcx_comm_create")
+        self.nranks, self.rank, self.device = nranks, rank, device
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_char * rcx.COMM_ID_BYTES)()
+        st = rcx.lib().rcx_comm_unique_id(buf)
+        if st != rcx.OK:
+            raise rcx.RcxError(st, "rcx_comm_unique_id")
+        return bytes(buf.raw)
+
+    @classmethod
+    def from_process_group(cls, device: int, group=None) -> "Comm":
+        """Rank 0 makes the id and torch.distributed carries it to the others (the "out of band" channel)."""
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        ident = [cls.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0, group=group)
+        return cls(device, ident[0], world, rank)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            rcx.lib().rcx_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def allgatherv(self, segment, offsets, concat, table=None, stream=None):
+        """rcx_allgatherv_segments: segment/offsets as the encoder wrote them -> concat (+ table) on every rank.
+        Returns (seg_base, block_base) as python lists of nranks+1."""
+        nblocks = offsets.numel() - 1
+        seg_base, block_base = (C.c_uint64 * (self.nranks + 1))(), (C.c_uint64 * (self.nranks + 1))()
+        st = rcx.lib().rcx_allgatherv_segments(self._h, segment.data_ptr(), offsets.data_ptr(), nblocks, concat.data_ptr(), concat.numel(),
+                                               table.data_ptr() if table is not None else None, table.numel() if table is not None else 0,
+                                               seg_base, block_base, rcx.Context._stream_handle(stream))
+        if st != rcx.OK:
+            raise rcx.RcxError(st, "rcx_allgatherv_segments")
+        return list(seg_base), list(block_base)

@@ -14,7 +14,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RCX_LIBRARY") or os.path.join(HERE, "librcx.so")  # RCX_LIBRARY: a diagnostic (stamped) build
 
-OK, PENDING, ERROR, E_ARG, E_CAPACITY, E_CORRUPT, E_HIP, E_NOMEM = 0, 1, -1, -2, -3, -4, -5, -6
+OK, PENDING, ERROR, E_ARG, E_CAPACITY, E_CORRUPT, E_HIP, E_NOMEM, E_COMM = 0, 1, -1, -2, -3, -4, -5, -6, -7
+COMM_ID_BYTES = 128
 CODER_ADAPTIVE, CODER_STATIC = 0, 1
 T_ENCODE, T_SCAN, T_SCATTER, T_DECODE, T_COUNT = 0, 1, 2, 3, 4
 MIN_BLOCK, MAX_BLOCK, MAX_STREAM = 16, (1 << 24) - 256, 0x7FFFFFFF
@@ -25,6 +26,8 @@ EXPORTS = (
     "rcx_block_count", "rcx_block_bound", "rcx_encode_bound", "rcx_encode_blocks_device", "rcx_decode_blocks_device",
     "rcx_encode_blocks", "rcx_decode_blocks", "rcx_stream_encode", "rcx_stream_decode", "rcx_ctx_set_timing",
     "rcx_ctx_get_timing", "rcx_ctx_last_redo",
+    "rcx_comm_unique_id", "rcx_comm_create", "rcx_comm_destroy", "rcx_comm_rank", "rcx_comm_size", "rcx_exchange_plan",
+    "rcx_allgatherv_segments",
 )
 
 
@@ -69,6 +72,14 @@ def lib() -> C.CDLL:
         L.rcx_ctx_set_timing.restype, L.rcx_ctx_set_timing.argtypes = i32, [vp, i32]
         L.rcx_ctx_get_timing.restype, L.rcx_ctx_get_timing.argtypes = i32, [vp, C.POINTER(C.c_double), C.POINTER(u64), i32]
         L.rcx_ctx_last_redo.restype, L.rcx_ctx_last_redo.argtypes = i32, [vp, u64, C.POINTER(u64)]
+        L.rcx_comm_unique_id.restype, L.rcx_comm_unique_id.argtypes = i32, [vp]
+        L.rcx_comm_create.restype, L.rcx_comm_create.argtypes = i32, [i32, vp, i32, i32, C.POINTER(vp)]
+        L.rcx_comm_destroy.restype, L.rcx_comm_destroy.argtypes = None, [vp]
+        L.rcx_comm_rank.restype, L.rcx_comm_rank.argtypes = i32, [vp]
+        L.rcx_comm_size.restype, L.rcx_comm_size.argtypes = i32, [vp]
+        L.rcx_exchange_plan.restype, L.rcx_exchange_plan.argtypes = i32, [vp, vp, i32, vp, vp]
+        L.rcx_allgatherv_segments.restype = i32
+        L.rcx_allgatherv_segments.argtypes = [vp, vp, vp, u64, vp, u64, vp, u64, vp, vp, vp]
         _lib = L
     return _lib
 

@@ -30,26 +30,74 @@ _GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__fil
 CANTERBURY_ARCHIVE = os.path.join(_GOLDEN_DIR, "cantrbry.tar.bz2")
 
 
+def _mt19937_draws(seed: int):
+    """std::mt19937(seed)'s 32-bit draws, a chunk at a time (numpy's MT19937 with the legacy init_genrand seeding is
+    that generator; about 7x faster than RandomState.bytes / .randint, same values)."""
+    bg = np.random.MT19937()
+    bg._legacy_seeding(seed)
+
+    def take(count: int) -> np.ndarray:
+        return bg.random_raw(count).astype(np.uint32)
+
+    return take
+
+
 def uniform(n: int, seed: int = 12345) -> np.ndarray:
     """n uniform random bytes."""
     words = (n + 3) // 4
-    raw = np.random.RandomState(seed).bytes(words * 4)
-    return np.frombuffer(raw, dtype=np.uint8)[:n].copy()
+    out = np.empty(words, dtype=np.uint32)
+    take = _mt19937_draws(seed)
+    step = 1 << 22
+    for at in range(0, words, step):
+        m = min(step, words - at)
+        out[at:at + m] = take(m)
+    return out.view(np.uint8)[:n].copy()
+
+
+_ZIPF_TABLES = None
+
+
+def _zipf_tables():
+    """Integer form of the inverse CDF: symbol = number of k with thr[k] <= draw, where thr[k] is the smallest draw d
+    with (d + 0.5) / 2**32 > cdf[k] -- exactly what np.searchsorted(cdf, u, side="left") counts.  Plus a lookup on the
+    top 16 bits of the draw that settles all but the ~255 boundary cells."""
+    global _ZIPF_TABLES
+    if _ZIPF_TABLES is None:
+        weights = 1.0 / np.arange(1, 257, dtype=np.float64)
+        cdf = np.cumsum(weights)
+        cdf /= cdf[-1]
+        thr = np.empty(256, dtype=np.uint64)
+        for k in range(256):
+            lo, hi = 0, 1 << 32  # smallest d in [0, 2^32] with (d + 0.5) / 2^32 > cdf[k]
+            while lo < hi:
+                mid = (lo + hi) // 2
+                if (np.float64(mid) + 0.5) / 4294967296.0 > cdf[k]:
+                    hi = mid
+                else:
+                    lo = mid + 1
+            thr[k] = lo
+        cells = np.arange(1 << 16, dtype=np.uint64) << np.uint64(16)
+        first = np.searchsorted(thr, cells, side="right")                    # symbol of the cell's first draw
+        last = np.searchsorted(thr, cells + np.uint64(0xFFFF), side="right")  # ... and of its last
+        _ZIPF_TABLES = (thr, np.minimum(first, 255).astype(np.uint8), first != last)
+    return _ZIPF_TABLES
 
 
 def zipf(n: int, seed: int = 12345) -> np.ndarray:
     """n Zipf(s=1) bytes over 256 symbols."""
-    weights = 1.0 / np.arange(1, 257, dtype=np.float64)
-    cdf = np.cumsum(weights)
-    cdf /= cdf[-1]
+    thr, cell_sym, cell_split = _zipf_tables()
     out = np.empty(n, dtype=np.uint8)
-    rs = np.random.RandomState(seed)
+    take = _mt19937_draws(seed)
     step = 1 << 22
     for at in range(0, n, step):
         m = min(step, n - at)
-        draws = rs.randint(0, 2 ** 32, size=m, dtype=np.uint32)
-        u = (draws.astype(np.float64) + 0.5) / 4294967296.0
-        out[at:at + m] = np.minimum(np.searchsorted(cdf, u, side="left"), 255).astype(np.uint8)
+        draws = take(m)
+        top = draws >> np.uint32(16)
+        sym = cell_sym[top]
+        hard = np.flatnonzero(cell_split[top])
+        if len(hard):
+            sym[hard] = np.minimum(np.searchsorted(thr, draws[hard].astype(np.uint64), side="right"), 255).astype(np.uint8)
+        out[at:at + m] = sym
     return out
 
 

@@ -50,7 +50,8 @@ enum {
     RCX_E_CAPACITY = -3, /* destination too small / a block outgrew its scratch slot */
     RCX_E_CORRUPT = -4,  /* a block's stream is truncated or its header disagrees with the layout */
     RCX_E_HIP = -5,      /* HIP runtime error, or no usable MI355X */
-    RCX_E_NOMEM = -6     /* device or host allocation failed */
+    RCX_E_NOMEM = -6,    /* device or host allocation failed */
+    RCX_E_COMM = -7      /* RCCL error */
 };
 
 /* Which coder a call uses.  With RCX_CODER_STATIC the single-stream entry points have the bool semantics of
@@ -148,6 +149,34 @@ int rcx_stream_encode(rcx_ctx* ctx, int coder, const uint8_t* src, uint32_t n,
                       uint8_t* dst, uint64_t dst_cap, uint64_t sink_capacity, uint64_t* dst_size, uint32_t* request_size);
 int rcx_stream_decode(rcx_ctx* ctx, int coder, const uint8_t* comp, uint64_t comp_size,
                       uint8_t* dst, uint64_t sink_capacity, uint64_t* dst_size, uint32_t* request_size);
+
+/*
+ * Multi-GPU (new; the reference has no multi-device code).  Blocks are independent, so n bytes are sharded over the
+ * GPUs of a node as contiguous block ranges and coded with the calls above, no collective involved.  The one real
+ * exchange of the path is putting the compressed segments of all GPUs -- and their block tables -- together on
+ * every GPU ("allgatherv"; RCCL has no such call): one process per GPU, one rcx_comm per process, RCCL over xGMI.
+ *   rcx_comm_unique_id   rank 0 makes an id (RCX_COMM_ID_BYTES bytes) and hands it to the other ranks out of band
+ *   rcx_comm_create      collective over the nranks processes: rank `rank` joins on GPU `device`
+ *   rcx_exchange_plan    pure function: exclusive prefix sums of what every rank brings (segment bytes, blocks)
+ *   rcx_allgatherv_segments   collective, enqueued on `stream` except for ONE host synchronisation (the sizes):
+ *       d_segment / d_offsets[nblocks+1]   this rank's compacted streams and their table, as rcx_encode_blocks_device
+ *                                          wrote them (offsets[nblocks] is the segment size; ranks may differ in nblocks)
+ *       d_concat (concat_cap bytes)        receives every rank's segment back to back, rank 0 first
+ *       d_table (table_cap entries, or NULL)  receives the table of the concatenation: sum(nblocks)+1 offsets into d_concat
+ *       seg_base_out / block_base_out      optional host arrays of nranks+1: where rank r's bytes / blocks start
+ *     Every rank must pass the same capacities: then RCX_E_CAPACITY is returned by all of them, before anything moves.
+ */
+#define RCX_COMM_ID_BYTES 128
+typedef struct rcx_comm rcx_comm;
+int rcx_comm_unique_id(void* id);
+int rcx_comm_create(int device, const void* id, int nranks, int rank, rcx_comm** out);
+void rcx_comm_destroy(rcx_comm* comm);
+int rcx_comm_rank(const rcx_comm* comm);
+int rcx_comm_size(const rcx_comm* comm);
+int rcx_exchange_plan(const uint64_t* seg_bytes, const uint64_t* nblocks, int nranks, uint64_t* seg_base, uint64_t* block_base);
+int rcx_allgatherv_segments(rcx_comm* comm, const void* d_segment, const uint64_t* d_offsets, uint64_t nblocks,
+                            void* d_concat, uint64_t concat_cap, uint64_t* d_table, uint64_t table_cap,
+                            uint64_t* seg_base_out, uint64_t* block_base_out, void* stream);
 
 /* Per-kernel device time of the calls made since the last reset, in milliseconds,
  * measured with HIP events on the stream the kernels ran on (off by default). */

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 CSV output under gpurun_out/ into the small tracked summaries in profiles/.
 
-    python profiles/summarize.py <tag> <stats_dir> [--pmc name=dir ...]
+    python profiles/summarize.py <tag> <stats_dir> [--config workload=uniform,bytes=1073741824,block=65536] [--pmc name=dir ...]
 
 <stats_dir> is a `rocprofv3 --kernel-trace --stats --output-format csv -d <dir>` directory;
 each --pmc dir is a separate `rocprofv3 --pmc ... --kernel-trace` pass (FETCH_SIZE and WRITE_SIZE
@@ -27,7 +27,15 @@ def short(name: str) -> str:
 
 def main():
     tag, stats_dir = sys.argv[1], sys.argv[2]
-    pmc_dirs = dict(a.split("=", 1) for a in sys.argv[4:]) if len(sys.argv) > 3 and sys.argv[3] == "--pmc" else {}
+    rest = sys.argv[3:]
+    config = {"workload": "uniform", "bytes": 1 << 30, "block": 65536}  # what bench.py runs by default
+    if rest and rest[0] == "--config":
+        for kv in rest[1].split(","):
+            k, v = kv.split("=", 1)
+            config[k] = int(v) if v.isdigit() else v
+        rest = rest[2:]
+    config["recorded"] = tag
+    pmc_dirs = dict(a.split("=", 1) for a in rest[1:]) if rest and rest[0] == "--pmc" else {}
     newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)
     stats = newest(os.path.join(stats_dir, "*", "*_kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats)))
@@ -49,8 +57,9 @@ def main():
         for k, c in agg.items():
             for name, v in c.items():
                 counters[k][name] = sum(v) / len(v)
-    out = {"_how": ("per-launch averages from separate rocprofv3 --pmc passes of `bench.py --steps 2 --warmup 1 --no-cpu-baseline` "
-                    "(1 GiB uniform, 64 KiB blocks). FETCH_SIZE / WRITE_SIZE are KiB; per MI355X_MICROARCH.md the gfx950 FETCH_SIZE "
+    out = {"_config": config,
+           "_how": ("per-launch averages from separate rocprofv3 --pmc passes of `bench.py --steps 2 --warmup 1 --no-cpu-baseline` "
+                    "on the workload in _config. FETCH_SIZE / WRITE_SIZE are KiB; per MI355X_MICROARCH.md the gfx950 FETCH_SIZE "
                     "is doubled (128-B requests are tallied at 64 B), WRITE_SIZE is taken as is. That correction is calibrated for "
                     "16-B-per-lane coalesced streams; these kernels read and write lane-strided pieces, so the absolute is approximate.")}
     for k, c in counters.items():
@@ -69,7 +78,7 @@ def main():
     for r in rows[:6]:
         print(short(r["Name"]), r["Calls"], r["AverageNs"])
     for k, e in out.items():
-        if k != "_how" and "hbm_bytes_per_launch" in e:
+        if not k.startswith("_") and "hbm_bytes_per_launch" in e:
             print(k, "HBM GiB/launch %.3f" % (e["hbm_bytes_per_launch"] / 2 ** 30))
 
 

@@ -32,30 +32,28 @@ def _worker(rank: int, world: int, port: int, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        block, per_rank_blocks = 4096, 24
-        nblocks = per_rank_blocks * world
-        whole = workloads.zipf(nblocks * block, 99)
+        block, nblocks = 4096, 49  # not divisible by the world size: the ranks bring different block counts
+        whole = workloads.zipf(nblocks * block - 1000, 99)  # and the last block is short
         first, last = parallel.shard_blocks(nblocks, world, rank)
-        assert (first, last) == (rank * per_rank_blocks, (rank + 1) * per_rank_blocks)
         shard = whole[first * block: last * block]
         chk = oracle_lib.oracle()
         slots, sizes = chk.encode_blocks(shard, block)
         payload, offsets = chk.compact(slots, sizes)
+        assert len(sizes) == last - first
         seg = torch.zeros(len(payload) + 8192, dtype=torch.uint8)
         seg[: len(payload)] = torch.from_numpy(payload)
         concat = torch.zeros(world * (len(payload) + 8192), dtype=torch.uint8)
-        bases, seg_sizes, works = parallel.allgatherv_segments(seg, len(payload), concat)
-        table = parallel.allgather_offsets(torch.from_numpy(offsets.astype(np.int64)), bases)
-        assert works == []
-        # the per-root broadcast form must give the same bytes
-        concat_b = torch.zeros_like(concat)
-        bases_b, sizes_b, works_b = parallel.allgatherv_segments(seg, len(payload), concat_b, method="broadcast")
-        for w in works_b:
-            w.wait()
-        assert bases_b == bases and sizes_b == seg_sizes and torch.equal(concat_b[: sum(seg_sizes)], concat[: sum(seg_sizes)])
-        assert seg_sizes[rank] == len(payload) and table.numel() == nblocks + 1
+        table = torch.zeros(nblocks + 1, dtype=torch.int64)
+        seg_base, block_base = parallel.allgatherv_p2p(seg, torch.from_numpy(offsets.astype(np.int64)), concat, table)
+        assert block_base == [parallel.shard_blocks(nblocks, world, r)[0] for r in range(world)] + [nblocks]
+        assert seg_base[rank + 1] - seg_base[rank] == len(payload)
         total = int(table[-1])
-        assert total == sum(seg_sizes)
+        assert total == seg_base[-1]
+        # buffers that are too small are refused on every rank alike, before anything moves
+        with pytest.raises(ValueError):
+            parallel.allgatherv_p2p(seg, torch.from_numpy(offsets.astype(np.int64)), concat[: total - 1], table)
+        with pytest.raises(ValueError):
+            parallel.allgatherv_p2p(seg, torch.from_numpy(offsets.astype(np.int64)), concat, table[:nblocks])
         # every rank can now decode the WHOLE buffer from the concatenated stream
         stream = concat[:total].numpy()
         tbl = table.numpy().astype(np.uint64)
@@ -74,6 +72,15 @@ def _worker(rank: int, world: int, port: int, ret):
         ret[rank] = f"{type(e).__name__}: {e}"
     finally:
         dist.destroy_process_group()
+
+
+def test_exchange_plan_is_the_librarys():
+    # rcx_exchange_plan (include/rcx.h): pure host arithmetic, callable without a GPU
+    from cpprcoder_amd import parallel, rcx
+    assert parallel.exchange_plan([10, 0, 7], [2, 0, 1]) == ([0, 10, 10, 17], [0, 2, 2, 3])
+    assert parallel.exchange_plan([5], [1]) == ([0, 5], [0, 1])
+    with pytest.raises(rcx.RcxError):
+        parallel.exchange_plan([1 << 63, 1 << 63], [1, 1])  # wraps
 
 
 def test_shard_blocks():
