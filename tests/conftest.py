@@ -23,7 +23,9 @@ def golden():
         blocks = json.load(f)["blocks"]
     with open(os.path.join(here, "long_streams.json")) as f:
         long_streams = json.load(f)
-    return {"kat": kat, "blocks": blocks, "long": long_streams}
+    with open(os.path.join(here, "rans.json")) as f:
+        rans = json.load(f)
+    return {"kat": kat, "blocks": blocks, "long": long_streams, "rans": rans}
 
 
 @pytest.fixture(scope="session")

@@ -22,6 +22,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libcpprcoder_ref.so")
+REF_ANS_SO = os.path.join(ORACLE_DIR, "_ref", "libcppans_ref.so")
+
+CODER_ADAPTIVE, CODER_STATIC, CODER_RANS, CODER_RANS8 = 0, 1, 2, 3
 
 SUCCESS, PENDING, ERROR = 0, 1, -1
 
@@ -37,8 +40,10 @@ def _u8(a) -> np.ndarray:
 
 
 class Checker:
-    def __init__(self, path: str, prefix: str, kind: str):
+    def __init__(self, path: str, prefix: str, kind: str, ans_path: str | None = None):
         self.lib = C.CDLL(path)
+        # rANS (cppans.h): in liboracle.so itself for the restatement, in its own library for the reference build
+        self.ans = C.CDLL(ans_path) if ans_path else (self.lib if prefix == "rco_" else None)
         self.prefix = prefix
         self.kind = kind  # "port" (restatement) or "reference"
         p, L = prefix, self.lib
@@ -66,6 +71,14 @@ class Checker:
         self._probe.argtypes = [u8p, C.c_uint64, u32p, u32p, u32p, u32p, C.c_uint32, u32p, u8p]
         self._script = getattr(L, p + "stream_script")
         self._script.restype, self._script.argtypes = C.c_int, [i32p, C.c_int, i32p]
+        if self.ans is not None:
+            A = self.ans
+            self._rebr = getattr(A, p + "rans_encode_block_range")
+            self._rebr.restype = C.c_int
+            self._rebr.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, u8p, C.c_uint64, u32p, C.c_int]
+            self._rdbr = getattr(A, p + "rans_decode_block_range")
+            self._rdbr.restype = C.c_int
+            self._rdbr.argtypes = [u8p, C.c_uint64, u32p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, u8p, C.c_int]
 
     # ---- one-shot streams -------------------------------------------------
     @staticmethod
@@ -107,10 +120,29 @@ class Checker:
         ok, out, size = self._oneshot(self._sdec, comp, sink_capacity)
         return bool(ok), out, size
 
+    # ---- rANS (cppans.h), one stream ---------------------------------------
+    def rans_encode(self, data, simd: bool = False) -> bytes:
+        """rANS::encode / encode_simd on one buffer -> the stream (the last `size` bytes of the reference's destination)."""
+        src = _u8(data)
+        slots, sizes = self.encode_blocks(src, max(len(src), 1), coder=CODER_RANS8 if simd else CODER_RANS)
+        return bytes(slots[0, : int(sizes[0])])
+
+    def rans_decode(self, comp, n: int, simd: bool = False):
+        """-> (ok, bytes)"""
+        c = _u8(comp)
+        slots = np.zeros((1, len(c) + 64), dtype=np.uint8)
+        slots[0, : len(c)] = c
+        out, ok = self.decode_blocks(slots, np.array([len(c)], np.uint32), max(n, 1), n, coder=CODER_RANS8 if simd else CODER_RANS)
+        return ok, out.tobytes()
+
     # ---- many blocks ------------------------------------------------------
     @staticmethod
-    def block_bound(block: int) -> int:
-        b = block + block // 32 + 1024 + (block // 8 if block > (1 << 20) else 0)
+    def block_bound(block: int, coder: int = 0) -> int:
+        if coder >= CODER_RANS:
+            # cppans.h:492-495 (2n + 1032) + 64: encode_simd's eight flushed states, and its 2 bytes per symbol for a
+            # block of one repeated byte (the renormalisation test of cppans.h:357 wraps to "always" for freq = 4096)
+            return (2 * block + 1032 + 64 + 15) & ~15
+        b = block + block // 32 + 2048 + (block // 8 if block > (1 << 20) else 0)
         return (b + 15) & ~15
 
     def encode_blocks(self, data, block: int, coder: int = 0, threads: int = 1):
@@ -119,13 +151,16 @@ class Checker:
         src = _u8(data)
         n = len(src)
         nblocks = (n + block - 1) // block
-        slot = self.block_bound(block)
+        slot = self.block_bound(block, coder)
         slots = np.zeros((nblocks, slot), dtype=np.uint8)
         sizes = np.zeros(nblocks, dtype=np.uint32)
         oks = []
 
         def work(first, last):
-            oks.append(self._ebr(src.ctypes.data, n, block, first, last, slots.ctypes.data, slot, sizes.ctypes.data, coder))
+            if coder >= CODER_RANS:
+                oks.append(self._rebr(src.ctypes.data, n, block, first, last, slots.ctypes.data, slot, sizes.ctypes.data, coder - CODER_RANS))
+            else:
+                oks.append(self._ebr(src.ctypes.data, n, block, first, last, slots.ctypes.data, slot, sizes.ctypes.data, coder))
 
         self._fan_out(work, nblocks, threads)
         if not all(oks):
@@ -140,7 +175,10 @@ class Checker:
         oks = []
 
         def work(first, last):
-            oks.append(self._dbr(slots.ctypes.data, slot, sizes.ctypes.data, block, n, first, last, out.ctypes.data, coder))
+            if coder >= CODER_RANS:
+                oks.append(self._rdbr(slots.ctypes.data, slot, sizes.ctypes.data, block, n, first, last, out.ctypes.data, coder - CODER_RANS))
+            else:
+                oks.append(self._dbr(slots.ctypes.data, slot, sizes.ctypes.data, block, n, first, last, out.ctypes.data, coder))
 
         self._fan_out(work, nblocks, threads)
         return out, all(oks)
@@ -191,7 +229,8 @@ class Checker:
 
 def build_oracle(force: bool = False) -> None:
     """Compile the C restatement (and the reference build when /root/reference exists)."""
-    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(ORACLE_DIR, "rc_oracle.c")):
+    sources = [os.path.join(ORACLE_DIR, f) for f in ("rc_oracle.c", "rans_oracle.c")]
+    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(f) for f in sources):
         subprocess.run(["make", "-C", ORACLE_DIR, "all"], check=True, capture_output=True)
     ref_header = os.environ.get("RCX_REFERENCE", "/root/reference")
     if os.path.exists(os.path.join(ref_header, "cpprcoder.h")):
@@ -211,7 +250,8 @@ def oracle() -> Checker:
 
 def reference() -> Checker | None:
     if "r" not in _cache:
-        _cache["r"] = Checker(REF_SO, "ref_", "reference") if os.path.exists(REF_SO) else None
+        _cache["r"] = (Checker(REF_SO, "ref_", "reference", REF_ANS_SO if os.path.exists(REF_ANS_SO) else None)
+                       if os.path.exists(REF_SO) else None)
     return _cache["r"]
 
 
