@@ -44,6 +44,8 @@ struct rcx_ctx {
     u64 slots_bytes = 0;
     u32* sizes = nullptr;
     u64 sizes_count = 0;
+    u32* starts = nullptr;      // rANS: where each block's stream begins in its slot (the encoders write backwards)
+    u64 starts_count = 0;
     u32* redo = nullptr;        // decode: blocks the quad kernel leaves to the one-lane kernel (corrupt input only)
     u64 redo_count = 0;
     DivEntry* divtab = nullptr;
@@ -181,11 +183,14 @@ int ensure_redo(rcx_ctx* c, u64 nblocks)
     return r;
 }
 
-int reserve(rcx_ctx* c, u64 n, u32 block)
+bool is_rans(int coder) { return coder == RCX_CODER_RANS || coder == RCX_CODER_RANS8; }
+bool coder_ok(int coder) { return coder == RCX_CODER_ADAPTIVE || coder == RCX_CODER_STATIC || is_rans(coder); }
+
+int reserve(rcx_ctx* c, u64 n, u32 block, int coder = RCX_CODER_ADAPTIVE)
 {
     const u64 nblocks = rcx_block_count(n, block);
-    const u64 slot = rcx_block_bound(block);
-    int r = ensure_divtab(c, block);
+    const u64 slot = rcx_block_bound_for(coder, block);
+    int r = is_rans(coder) ? RCX_OK : ensure_divtab(c, block);
     if (r != RCX_OK) return r;
     r = grow(reinterpret_cast<void**>(&c->slots), &c->slots_bytes, nblocks * slot + 256);
     if (r != RCX_OK) return r;
@@ -193,6 +198,12 @@ int reserve(rcx_ctx* c, u64 n, u32 block)
     r = grow(reinterpret_cast<void**>(&c->sizes), &bytes, (nblocks + 1) * sizeof(u32));
     if (r != RCX_OK) return r;
     c->sizes_count = bytes / sizeof(u32);
+    if (is_rans(coder)) {
+        bytes = c->starts_count * sizeof(u32);
+        r = grow(reinterpret_cast<void**>(&c->starts), &bytes, (nblocks + 1) * sizeof(u32));
+        if (r != RCX_OK) return r;
+        c->starts_count = bytes / sizeof(u32);
+    }
     return ensure_redo(c, nblocks);
 }
 
@@ -226,12 +237,20 @@ uint64_t rcx_block_count(uint64_t n, uint32_t block) { return block ? (n + block
 // The static coder needs 521 + n + slack.  Rounded to 16 so slots keep 16-byte alignment.
 uint64_t rcx_block_bound(uint32_t block)
 {
-    uint64_t b = (uint64_t)block + block / 32 + 1024;
+    uint64_t b = (uint64_t)block + block / 32 + 2048;
     if (block > (1u << 20)) b += block / 8;
     return (b + 15) & ~(uint64_t)15;
 }
 
 uint64_t rcx_encode_bound(uint64_t n, uint32_t block) { return rcx_block_count(n, block) * rcx_block_bound(block) + 16; }
+
+uint64_t rcx_block_bound_for(int coder, uint32_t block)
+{
+    if (!is_rans(coder)) return rcx_block_bound(block);
+    return (2 * (uint64_t)block + 1032 + 64 + 15) & ~(uint64_t)15; // cppans.h:492-495 + 64, see rcx.h
+}
+
+uint64_t rcx_encode_bound_for(int coder, uint64_t n, uint32_t block) { return rcx_block_count(n, block) * rcx_block_bound_for(coder, block) + 16; }
 
 int rcx_ctx_create(int device, rcx_ctx** out)
 {
@@ -279,6 +298,7 @@ void rcx_ctx_destroy(rcx_ctx* c)
     }
     if (c->slots) (void)hipFree(c->slots);
     if (c->sizes) (void)hipFree(c->sizes);
+    if (c->starts) (void)hipFree(c->starts);
     if (c->redo) (void)hipFree(c->redo);
     if (c->divtab) (void)hipFree(c->divtab);
     if (c->status) (void)hipFree(c->status);
@@ -294,6 +314,13 @@ int rcx_ctx_reserve(rcx_ctx* c, uint64_t n, uint32_t block)
     if (!c || !block_ok(block)) return RCX_E_ARG;
     HIP_TRY(hipSetDevice(c->device));
     return reserve(c, n, block);
+}
+
+int rcx_ctx_reserve_for(rcx_ctx* c, int coder, uint64_t n, uint32_t block)
+{
+    if (!c || !block_ok(block) || !coder_ok(coder)) return RCX_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    return reserve(c, n, block, coder);
 }
 
 int rcx_ctx_sync_status(rcx_ctx* c, void* stream, uint64_t* first_bad_block)
@@ -319,22 +346,31 @@ int rcx_encode_blocks_device(rcx_ctx* c, int coder, const void* d_src, uint64_t 
                              void* d_dst, uint64_t dst_cap, uint64_t* d_offsets, void* stream)
 {
     if (!c || !block_ok(block) || !d_offsets || (n && (!d_src || !d_dst))) return RCX_E_ARG;
-    if (coder != RCX_CODER_ADAPTIVE && coder != RCX_CODER_STATIC) return RCX_E_ARG;
+    if (!coder_ok(coder)) return RCX_E_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(c->device));
     const u64 nblocks = rcx_block_count(n, block);
     if (nblocks == 0) return hipMemsetAsync(d_offsets, 0, sizeof(u64), s) == hipSuccess ? RCX_OK : RCX_E_HIP;
     if (nblocks > 0x7FFFFFFFull) return RCX_E_ARG; // grid.x limit with 8 blocks per workgroup to spare
-    int r = reserve(c, n, block);
+    int r = reserve(c, n, block, coder);
     if (r != RCX_OK) return r;
-    const u64 slot = rcx_block_bound(block);
+    const u64 slot = rcx_block_bound_for(coder, block);
     // Static coder: with fewer than 32768 blocks (two one-wave workgroups per CU) the three-wave kernel, which
     // spreads 64 blocks over three SIMDs, is faster (157 vs 112 GB/s at 16384 blocks); with more, the one-wave
     // kernel fills the machine by itself (202 vs 157 GB/s at 32768 blocks).
     const bool static3 = coder == RCX_CODER_STATIC && c->enc_variant >= 2 && nblocks < 32768;
     {
         Timed t(c, s, RCX_T_ENCODE);
-        if (static3) {
+        if (is_rans(coder)) { // cppans.h: a block is an octet of lanes, four 8-block waves per workgroup
+            const u64 per_wg = 4 * RCX_RANS_BLOCKS;
+            const u32 grid = (u32)((nblocks + per_wg - 1) / per_wg);
+            if (coder == RCX_CODER_RANS8)
+                hipLaunchKernelGGL(rcx_enc_rans_k<true>, dim3(grid), dim3(256), 0, s, static_cast<const u8*>(d_src), n, block, nblocks, c->slots,
+                                   slot, c->sizes, c->starts, c->status);
+            else
+                hipLaunchKernelGGL(rcx_enc_rans_k<false>, dim3(grid), dim3(256), 0, s, static_cast<const u8*>(d_src), n, block, nblocks, c->slots,
+                                   slot, c->sizes, c->starts, c->status);
+        } else if (static3) {
             const u32 lanes = encode_lanes(c, nblocks);
             const u32 grid = (u32)((nblocks + lanes - 1) / lanes);
             hipLaunchKernelGGL(rcx_enc_static3_k, dim3(grid), dim3(RCX_ST3_THREADS), 0, s, static_cast<const u8*>(d_src), n, block,
@@ -385,7 +421,7 @@ int rcx_encode_blocks_device(rcx_ctx* c, int coder, const void* d_src, uint64_t 
     {
         Timed t(c, s, RCX_T_SCATTER);
         hipLaunchKernelGGL(rcx_scatter_k, dim3((u32)nblocks), dim3(256), 0, s, c->slots, slot, c->sizes, d_offsets,
-                           static_cast<u8*>(d_dst), dst_cap);
+                           static_cast<u8*>(d_dst), dst_cap, is_rans(coder) ? static_cast<const u32*>(c->starts) : static_cast<const u32*>(nullptr));
     }
     return hipGetLastError() == hipSuccess ? RCX_OK : RCX_E_HIP;
 }
@@ -395,12 +431,24 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
                              uint64_t n, void* d_dst, void* stream)
 {
     if (!c || !block_ok(block) || (nblocks && (!d_comp || !d_offsets || !d_dst))) return RCX_E_ARG;
-    if (coder != RCX_CODER_ADAPTIVE && coder != RCX_CODER_STATIC) return RCX_E_ARG;
+    if (!coder_ok(coder)) return RCX_E_ARG;
     if (nblocks != rcx_block_count(n, block)) return RCX_E_ARG;
     if (nblocks == 0) return RCX_OK;
     if (nblocks > 0x7FFFFFFFull) return RCX_E_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(c->device));
+    if (is_rans(coder)) {
+        Timed t(c, s, RCX_T_DECODE);
+        const u64 per_wg = 4 * RCX_RANS_BLOCKS;
+        const u32 grid = (u32)((nblocks + per_wg - 1) / per_wg);
+        if (coder == RCX_CODER_RANS8)
+            hipLaunchKernelGGL(rcx_dec_rans8_k<4>, dim3(grid), dim3(256), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks,
+                               block, n, static_cast<u8*>(d_dst), c->status);
+        else
+            hipLaunchKernelGGL(rcx_dec_rans1_k<4>, dim3(grid), dim3(256), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks,
+                               block, n, static_cast<u8*>(d_dst), c->status);
+        return hipGetLastError() == hipSuccess ? RCX_OK : RCX_E_HIP;
+    }
     int r = ensure_divtab(c, block);
     if (r != RCX_OK) return r;
     const bool quad = coder == RCX_CODER_ADAPTIVE && decode_lanes(c, nblocks) == 4;
@@ -475,8 +523,9 @@ int rcx_encode_blocks(rcx_ctx* c, int coder, const uint8_t* src, uint64_t n, uin
     if (!c || !block_ok(block) || !dst_size || (n && (!src || !dst))) return RCX_E_ARG;
     HIP_TRY(hipSetDevice(c->device));
     *dst_size = 0;
+    if (!coder_ok(coder)) return RCX_E_ARG;
     const u64 nblocks = rcx_block_count(n, block);
-    const u64 bound = rcx_encode_bound(n, block);
+    const u64 bound = rcx_encode_bound_for(coder, n, block);
     int r = grow(reinterpret_cast<void**>(&c->h_in), &c->h_in_bytes, n + 64);
     if (r != RCX_OK) return r;
     r = grow(reinterpret_cast<void**>(&c->h_out), &c->h_out_bytes, bound + 64);
@@ -543,10 +592,38 @@ int rcx_stream_encode(rcx_ctx* c, int coder, const uint8_t* src, uint32_t n,
                       uint8_t* dst, uint64_t dst_cap, uint64_t sink_capacity, uint64_t* dst_size, uint32_t* request_size)
 {
     if (!c || !dst || !dst_size || (n && !src)) return RCX_E_ARG;
-    if ((coder != RCX_CODER_ADAPTIVE && coder != RCX_CODER_STATIC) || n > RCX_MAX_STREAM) return RCX_E_ARG;
+    if (!coder_ok(coder) || n > RCX_MAX_STREAM) return RCX_E_ARG;
     HIP_TRY(hipSetDevice(c->device));
     *dst_size = 0;
     if (request_size) *request_size = 0;
+    if (is_rans(coder)) {
+        // rANS::encode / encode_simd (cppans.h:497-530, :567-607): one block; RCX_ERROR where the reference returns 0
+        // (it asserts 0 < src_size; its destination cannot be larger than u32 either)
+        if (n == 0 || n > RCX_MAX_RANS_STREAM) return RCX_ERROR;
+        const u32 rblock = n < RCX_MIN_BLOCK ? RCX_MIN_BLOCK : n;
+        int rr = reserve(c, rblock, rblock, coder);
+        if (rr != RCX_OK) return rr;
+        rr = grow(reinterpret_cast<void**>(&c->h_in), &c->h_in_bytes, (u64)n + 64);
+        if (rr != RCX_OK) return rr;
+        HIP_TRY(hipMemcpy(c->h_in, src, n, hipMemcpyHostToDevice));
+        const u64 rslot = rcx_block_bound_for(coder, rblock);
+        if (coder == RCX_CODER_RANS8)
+            hipLaunchKernelGGL(rcx_enc_rans_k<true>, dim3(1), dim3(256), 0, nullptr, c->h_in, (u64)n, rblock, (u64)1, c->slots, rslot, c->sizes,
+                               c->starts, c->status);
+        else
+            hipLaunchKernelGGL(rcx_enc_rans_k<false>, dim3(1), dim3(256), 0, nullptr, c->h_in, (u64)n, rblock, (u64)1, c->slots, rslot, c->sizes,
+                               c->starts, c->status);
+        if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
+        rr = rcx_ctx_sync_status(c, nullptr, nullptr);
+        if (rr != RCX_OK) return rr;
+        u32 rsize = 0, rstart = 0;
+        HIP_TRY(hipMemcpy(&rsize, c->sizes, sizeof(u32), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&rstart, c->starts, sizeof(u32), hipMemcpyDeviceToHost));
+        *dst_size = rsize;
+        if (rsize > sink_capacity || rsize > dst_cap) return RCX_E_CAPACITY;
+        HIP_TRY(hipMemcpy(dst, c->slots + rstart, rsize, hipMemcpyDeviceToHost));
+        return RCX_OK;
+    }
     const u32 block = n < RCX_MIN_BLOCK ? RCX_MIN_BLOCK : n;
     const bool longer = n > RCX_MAX_BLOCK; // past the table halving of cpprcoder.h:1138: the lane divides by its own total
     const u64 slot = rcx_block_bound(block);
@@ -618,10 +695,37 @@ int rcx_stream_decode(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
                       uint8_t* dst, uint64_t sink_capacity, uint64_t* dst_size, uint32_t* request_size)
 {
     if (!c || !dst || !dst_size || (comp_size && !comp)) return RCX_E_ARG;
-    if ((coder != RCX_CODER_ADAPTIVE && coder != RCX_CODER_STATIC) || comp_size > 0xFFFFFFFFull) return RCX_E_ARG;
+    if (!coder_ok(coder) || comp_size > 0xFFFFFFFFull) return RCX_E_ARG;
     HIP_TRY(hipSetDevice(c->device));
     *dst_size = 0;
     if (request_size) *request_size = 0;
+    if (is_rans(coder)) {
+        // rANS::decode / decode_simd (cppans.h:532-564, :609-649): RCX_ERROR where the reference returns 0 (or would
+        // leave its arrays: a header that is not a scaled cumulative table, a payload that runs out)
+        if (comp_size < 1032 + 4) return RCX_ERROR;
+        const u32 declared = (u32)comp[0] | ((u32)comp[1] << 8) | ((u32)comp[2] << 16) | ((u32)comp[3] << 24);
+        if (declared > sink_capacity || declared == 0 || declared > RCX_MAX_RANS_STREAM) return RCX_ERROR; // :541, :618
+        const u32 rblock = declared < RCX_MIN_BLOCK ? RCX_MIN_BLOCK : declared;
+        int rr = grow(reinterpret_cast<void**>(&c->h_in), &c->h_in_bytes, comp_size + 64);
+        if (rr != RCX_OK) return rr;
+        rr = grow(reinterpret_cast<void**>(&c->h_out), &c->h_out_bytes, (u64)declared + 64);
+        if (rr != RCX_OK) return rr;
+        u64 roff_bytes = c->h_off_count * sizeof(u64);
+        rr = grow(reinterpret_cast<void**>(&c->h_off), &roff_bytes, 2 * sizeof(u64));
+        if (rr != RCX_OK) return rr;
+        c->h_off_count = roff_bytes / sizeof(u64);
+        const u64 roffs[2] = {0, comp_size};
+        HIP_TRY(hipMemcpy(c->h_in, comp, comp_size, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->h_off, roffs, sizeof(roffs), hipMemcpyHostToDevice));
+        rr = rcx_decode_blocks_device(c, coder, c->h_in, comp_size, c->h_off, 1, rblock, declared, c->h_out, nullptr);
+        if (rr != RCX_OK) return rr;
+        rr = rcx_ctx_sync_status(c, nullptr, nullptr);
+        if (rr == RCX_E_CORRUPT) return RCX_ERROR;
+        if (rr != RCX_OK) return rr;
+        HIP_TRY(hipMemcpy(dst, c->h_out, declared, hipMemcpyDeviceToHost));
+        *dst_size = declared;
+        return RCX_OK;
+    }
     if (coder == RCX_CODER_STATIC) {
         // RangeEncoder<T>::decode (cpprcoder.h:460-519): bool.  RCX_OK = true; RCX_ERROR = false, with the
         // symbols written before the failure in dst; a full sink is the caller's to notice (it replays writeByte).

@@ -177,30 +177,33 @@ __global__ __launch_bounds__(1024) void rcx_scan_sizes_k(const u32* __restrict__
 // words are byte-shifted into place.
 // ===========================================================================
 __global__ __launch_bounds__(256) void rcx_scatter_k(const u8* __restrict__ slots, u64 slot, const u32* __restrict__ sizes,
-                                                     const u64* __restrict__ offsets, u8* __restrict__ dst, u64 dst_cap)
+                                                     const u64* __restrict__ offsets, u8* __restrict__ dst, u64 dst_cap,
+                                                     const u32* __restrict__ starts)
 {
     const u64 blk = blockIdx.x;
     const u32 size = sizes[blk];
     const u64 off = offsets[blk];
     if (off + size > dst_cap) return; // flagged by the scan
-    const u8* s = slots + blk * slot;
+    // the stream begins at the start of its slot (range coders) or wherever the backward-writing rANS encoders got to
+    const u8* s = slots + blk * slot + (starts ? starts[blk] : 0u);
     u8* d = dst + off;
     const u32 tid = threadIdx.x;
     u32 head = (u32)((0 - reinterpret_cast<uintptr_t>(d)) & 15u);
     if (head > size) head = size;
     if (tid < head) d[tid] = s[tid];
     const u32 nvec = (size - head) >> 4;
-    const u32 sh = head & 3u;
+    const uintptr_t from = reinterpret_cast<uintptr_t>(s) + head;
+    const u32 sh = (u32)(from & 3u);
+    const u32* w0p = reinterpret_cast<const u32*>(from & ~(uintptr_t)3);
     for (u32 v = tid; v < nvec; v += 256) {
-        const u32 sp = head + 16u * v;
-        const u32* w = reinterpret_cast<const u32*>(s + (sp & ~3u));
+        const u32* w = w0p + 4 * v;
         const u32 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
         U4 out;
         out.x = __builtin_amdgcn_alignbyte(w1, w0, sh);
         out.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
         out.z = __builtin_amdgcn_alignbyte(w3, w2, sh);
         out.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
-        *reinterpret_cast<U4*>(d + sp) = out;
+        *reinterpret_cast<U4*>(d + head + 16u * v) = out;
     }
     const u32 done = head + (nvec << 4);
     if (tid < size - done) d[done + tid] = s[done + tid];
@@ -334,3 +337,4 @@ __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ 
 
 #include "rcx_oct.hpp"
 #include "rcx_static.hpp"
+#include "rcx_rans.hpp"

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("RCX_LIBRARY") or os.path.join(HERE, "librcx.so")  # R
 
 OK, PENDING, ERROR, E_ARG, E_CAPACITY, E_CORRUPT, E_HIP, E_NOMEM, E_COMM = 0, 1, -1, -2, -3, -4, -5, -6, -7
 COMM_ID_BYTES = 128
-CODER_ADAPTIVE, CODER_STATIC = 0, 1
+CODER_ADAPTIVE, CODER_STATIC, CODER_RANS, CODER_RANS8 = 0, 1, 2, 3
 T_ENCODE, T_SCAN, T_SCATTER, T_DECODE, T_COUNT = 0, 1, 2, 3, 4
 MIN_BLOCK, MAX_BLOCK, MAX_STREAM = 16, (1 << 24) - 256, 0x7FFFFFFF
 
@@ -26,6 +26,7 @@ EXPORTS = (
     "rcx_block_count", "rcx_block_bound", "rcx_encode_bound", "rcx_encode_blocks_device", "rcx_decode_blocks_device",
     "rcx_encode_blocks", "rcx_decode_blocks", "rcx_stream_encode", "rcx_stream_decode", "rcx_ctx_set_timing",
     "rcx_ctx_get_timing", "rcx_ctx_last_redo",
+    "rcx_block_bound_for", "rcx_encode_bound_for", "rcx_ctx_reserve_for",
     "rcx_comm_unique_id", "rcx_comm_create", "rcx_comm_destroy", "rcx_comm_rank", "rcx_comm_size", "rcx_exchange_plan",
     "rcx_allgatherv_segments",
 )
@@ -57,6 +58,9 @@ def lib() -> C.CDLL:
         L.rcx_block_count.restype, L.rcx_block_count.argtypes = u64, [u64, u32]
         L.rcx_block_bound.restype, L.rcx_block_bound.argtypes = u64, [u32]
         L.rcx_encode_bound.restype, L.rcx_encode_bound.argtypes = u64, [u64, u32]
+        L.rcx_block_bound_for.restype, L.rcx_block_bound_for.argtypes = u64, [i32, u32]
+        L.rcx_encode_bound_for.restype, L.rcx_encode_bound_for.argtypes = u64, [i32, u64, u32]
+        L.rcx_ctx_reserve_for.restype, L.rcx_ctx_reserve_for.argtypes = i32, [vp, i32, u64, u32]
         L.rcx_encode_blocks_device.restype = i32
         L.rcx_encode_blocks_device.argtypes = [vp, i32, vp, u64, u32, vp, u64, vp, vp]
         L.rcx_decode_blocks_device.restype = i32
@@ -92,12 +96,12 @@ def block_count(n: int, block: int) -> int:
     return int(lib().rcx_block_count(n, block))
 
 
-def block_bound(block: int) -> int:
-    return int(lib().rcx_block_bound(block))
+def block_bound(block: int, coder: int = CODER_ADAPTIVE) -> int:
+    return int(lib().rcx_block_bound_for(coder, block))
 
 
-def encode_bound(n: int, block: int) -> int:
-    return int(lib().rcx_encode_bound(n, block))
+def encode_bound(n: int, block: int, coder: int = CODER_ADAPTIVE) -> int:
+    return int(lib().rcx_encode_bound_for(coder, n, block))
 
 
 def _check(status: int, where: str) -> None:
@@ -130,8 +134,8 @@ class Context:
         except Exception:
             pass
 
-    def reserve(self, n: int, block: int) -> None:
-        _check(lib().rcx_ctx_reserve(self._h, n, block), "rcx_ctx_reserve")
+    def reserve(self, n: int, block: int, coder: int = CODER_ADAPTIVE) -> None:
+        _check(lib().rcx_ctx_reserve_for(self._h, coder, n, block), "rcx_ctx_reserve_for")
 
     # ---- device pointers (torch tensors as HBM) ---------------------------
     @staticmethod
@@ -170,7 +174,7 @@ class Context:
         src = _np_u8(data)
         n = len(src)
         nblocks = block_count(n, block)
-        dst = np.zeros(encode_bound(n, block), dtype=np.uint8)
+        dst = np.zeros(encode_bound(n, block, coder), dtype=np.uint8)
         offsets = np.zeros(nblocks + 1, dtype=np.uint64)
         size = C.c_uint64()
         st = lib().rcx_encode_blocks(self._h, coder, src.ctypes.data, n, block, dst.ctypes.data, len(dst), C.byref(size),
@@ -195,7 +199,7 @@ class Context:
         """-> (status, request_size, stream bytes).  dst_cap: size of the buffer handed to the library (default: exactly
         what include/rcx.h says is needed, with canary bytes behind it that must survive)."""
         src = _np_u8(data)
-        bound = block_bound(max(len(src), MIN_BLOCK))
+        bound = block_bound(max(len(src), MIN_BLOCK), coder)
         cap = bound if sink_capacity is None else sink_capacity
         room = min(max(cap, 4) + 4, bound) if dst_cap is None else dst_cap
         dst = np.full(room + 64, 0xA5, dtype=np.uint8)

@@ -60,7 +60,14 @@ enum {
  * failure; request_size is not used. */
 enum {
     RCX_CODER_ADAPTIVE = 0, /* AdaptiveRangeEncoder/Decoder, cpprcoder.h:626-940 */
-    RCX_CODER_STATIC = 1    /* RangeEncoder (two-pass, 516-byte table header), cpprcoder.h:321-619 */
+    RCX_CODER_STATIC = 1,   /* RangeEncoder (two-pass, 516-byte table header), cpprcoder.h:321-619 */
+    /* The reference's rANS siblings (cppans.h).  A block's stream is what rANS::encode / encode_simd return for that
+     * block alone (the last `size` bytes of their destination, test/main.cpp:384-387):
+     * [u32 LE n][257 x u32 LE scaled cumulative counts][payload].  With these coders the single-stream entry points
+     * have the semantics of the reference's static functions: encode hands back the stream, decode the n symbols;
+     * RCX_ERROR where the reference returns 0. */
+    RCX_CODER_RANS = 2,     /* rANS::encode / decode, cppans.h:497-563: one state, 14-bit probabilities, bytes */
+    RCX_CODER_RANS8 = 3     /* rANS::encode_simd / decode_simd, cppans.h:567-649: 8 interleaved states, 12-bit, 16-bit words */
 };
 
 #define RCX_MIN_BLOCK 16u
@@ -70,6 +77,7 @@ enum {
  * MAX_SIZE (cpprcoder.h:329): past RCX_MAX_BLOCK symbols the lane keeps its own total and halves the table. */
 #define RCX_MAX_BLOCK ((1u << 24) - 256u)
 #define RCX_MAX_STREAM 0x7FFFFFFFu
+#define RCX_MAX_RANS_STREAM 0x7FFFFB00u /* rANS single streams: 2n + 1096 must fit the u32 sizes of cppans.h:72-76 */
 
 typedef struct rcx_ctx rcx_ctx;
 
@@ -83,6 +91,7 @@ void rcx_ctx_destroy(rcx_ctx* ctx);
 /* Pre-allocate scratch for buffers up to n bytes at this block size (otherwise the
  * first call that needs more allocates, which is not allowed under graph capture). */
 int rcx_ctx_reserve(rcx_ctx* ctx, uint64_t n, uint32_t block);
+int rcx_ctx_reserve_for(rcx_ctx* ctx, int coder, uint64_t n, uint32_t block); /* the same for a given coder (rANS slots are larger) */
 /* Wait for `stream`, then return and clear the latched device-side status:
  * RCX_OK, RCX_E_CAPACITY or RCX_E_CORRUPT; *first_bad_block (optional) gets the
  * lowest failing block index. */
@@ -90,8 +99,13 @@ int rcx_ctx_sync_status(rcx_ctx* ctx, void* stream, uint64_t* first_bad_block);
 
 /* Geometry helpers (pure functions). */
 uint64_t rcx_block_count(uint64_t n, uint32_t block);   /* ceil(n / block) */
-uint64_t rcx_block_bound(uint32_t block);               /* bytes reserved for one block's stream */
-uint64_t rcx_encode_bound(uint64_t n, uint32_t block);  /* safe dst_cap for the compacted streams */
+uint64_t rcx_block_bound(uint32_t block);               /* bytes reserved for one block's stream (the range coders) */
+uint64_t rcx_encode_bound(uint64_t n, uint32_t block);  /* safe dst_cap for the compacted streams (the range coders) */
+/* The same per coder.  The rANS coders get the reference's own bound (rANS::calc_encoded_size, cppans.h:492-495:
+ * 2n + 1032) + 64: encode_simd spends 2 bytes per symbol on a block of one repeated byte (the renormalisation test
+ * of cppans.h:357 wraps to "always" for a frequency of 4096), and its eight flushed states need room even when n < 16. */
+uint64_t rcx_block_bound_for(int coder, uint32_t block);
+uint64_t rcx_encode_bound_for(int coder, uint64_t n, uint32_t block);
 
 /*
  * Encode n bytes as independent blocks on the GPU.

@@ -35,7 +35,7 @@ def gpu_encode(ctx, data, block, src_offset=0, coder=0):
     buf[src_offset:src_offset + n] = torch.from_numpy(data).cuda()
     src = buf[src_offset:src_offset + n]
     nblocks = rcx.block_count(n, block)
-    dst = torch.zeros(rcx.encode_bound(n, block), dtype=torch.uint8, device="cuda")
+    dst = torch.zeros(rcx.encode_bound(n, block, coder), dtype=torch.uint8, device="cuda")
     offs = torch.zeros(nblocks + 1, dtype=torch.int64, device="cuda")
     ctx.encode_blocks_device(src, block, dst, offs, coder=coder)
     ctx.sync_status()

@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "sweep.jsonl"))
     ap.add_argument("--workloads", default="uniform,canterbury,zipf")
     ap.add_argument("--blocks", default="4096,8192,16384,32768,65536,131072,262144")
-    ap.add_argument("--coder", type=int, default=0, help="0 adaptive, 1 static")
+    ap.add_argument("--coder", type=int, default=0, help="0 adaptive, 1 static, 2 rANS (one state), 3 rANS (eight states)")
     args = ap.parse_args()
     import torch
     from cpprcoder_amd import rcx, workloads
@@ -36,10 +36,10 @@ def main():
             gen_s = time.time() - t0
             for block in [int(b) for b in args.blocks.split(",")]:
                 nblocks = rcx.block_count(n, block)
-                dst = torch.empty(rcx.encode_bound(n, block), dtype=torch.uint8, device="cuda")
+                dst = torch.empty(rcx.encode_bound(n, block, args.coder), dtype=torch.uint8, device="cuda")
                 offs = torch.zeros(nblocks + 1, dtype=torch.int64, device="cuda")
                 out = torch.empty(n, dtype=torch.uint8, device="cuda")
-                ctx.reserve(n, block)
+                ctx.reserve(n, block, args.coder)
                 enc_ms, dec_ms = [], []
                 for rep in range(4):
                     ctx.set_timing(True)
@@ -54,7 +54,7 @@ def main():
                 ok = bool(torch.equal(out, src))
                 total = int(offs[-1])
                 e, d = sorted(enc_ms)[1], sorted(dec_ms)[1]
-                line = {"coder": ("adaptive", "static")[args.coder], "workload": wl, "bytes": n, "block": block, "blocks": nblocks, "ratio": round(total / n, 6),
+                line = {"coder": ("adaptive", "static", "rans", "rans8")[args.coder], "workload": wl, "bytes": n, "block": block, "blocks": nblocks, "ratio": round(total / n, 6),
                         "encode_ms": round(e, 3), "decode_ms": round(d, 3), "encode_MBps": round(n / 1e6 / (e * 1e-3), 1),
                         "decode_MBps": round(n / 1e6 / (d * 1e-3), 1), "roundtrip_MBps": round(n / 1e6 / ((e + d) * 1e-3), 1),
                         "roundtrip_ok": ok, "gen_s": round(gen_s, 1)}
