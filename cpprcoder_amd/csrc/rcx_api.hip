@@ -39,6 +39,7 @@ struct rcx_ctx {
     int enc_lanes = 0;       // blocks per multi-wave encode workgroup: 0 = from the block count, else 1..64 (RCX_ENC_LANES)
     int dec_quads = 0;       // blocks per quad-decoder wave: 0 = from the block count, else 1, 2, 4, 8, 16 (RCX_DEC_QUADS)
     int cus = 256;           // compute units of the device
+    bool rans_track = false; // the single-stream rANS decode wants the payload bytes consumed (status[2])
     // scratch
     u8* slots = nullptr;
     u64 slots_bytes = 0;
@@ -446,7 +447,7 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
                                block, n, static_cast<u8*>(d_dst), c->status);
         else
             hipLaunchKernelGGL(rcx_dec_rans1_k<4>, dim3(grid), dim3(256), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks,
-                               block, n, static_cast<u8*>(d_dst), c->status);
+                               block, n, static_cast<u8*>(d_dst), c->status, c->rans_track ? c->status + 2 : static_cast<u32*>(nullptr));
         return hipGetLastError() == hipSuccess ? RCX_OK : RCX_E_HIP;
     }
     int r = ensure_divtab(c, block);
@@ -717,13 +718,22 @@ int rcx_stream_decode(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
         const u64 roffs[2] = {0, comp_size};
         HIP_TRY(hipMemcpy(c->h_in, comp, comp_size, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->h_off, roffs, sizeof(roffs), hipMemcpyHostToDevice));
+        c->rans_track = true;
         rr = rcx_decode_blocks_device(c, coder, c->h_in, comp_size, c->h_off, 1, rblock, declared, c->h_out, nullptr);
+        c->rans_track = false;
         if (rr != RCX_OK) return rr;
         rr = rcx_ctx_sync_status(c, nullptr, nullptr);
         if (rr == RCX_E_CORRUPT) return RCX_ERROR;
         if (rr != RCX_OK) return rr;
         HIP_TRY(hipMemcpy(dst, c->h_out, declared, hipMemcpyDeviceToHost));
         *dst_size = declared;
+        if (request_size) { // what the reference returns: payload bytes consumed (decode) / the symbol count (decode_simd)
+            *request_size = declared;
+            if (coder == RCX_CODER_RANS) {
+                HIP_TRY(hipMemcpy(c->status_host, c->status, 4 * sizeof(u32), hipMemcpyDeviceToHost));
+                *request_size = c->status_host[2];
+            }
+        }
         return RCX_OK;
     }
     if (coder == RCX_CODER_STATIC) {

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_rans8_k(const u8* __restri
 // against their upper bounds (cum2sym of cppans.h:545-550 would be 16 KiB per block).
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void rcx_dec_rans1_k(const u8* __restrict__ comp, u64 comp_size, const u64* __restrict__ offsets,
-                                                             u64 nblocks, u32 block, u64 n, u8* __restrict__ dst, u32* status)
+                                                             u64 nblocks, u32 block, u64 n, u8* __restrict__ dst, u32* status, u32* track)
 {
     __shared__ __attribute__((aligned(16))) u8 lds_all[WAVES * RCX_RANS_BLOCKS * RCX_RANS1_DEC_LDS_BYTES];
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -412,10 +412,9 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_rans1_k(const u8* __restri
     bool ran_dry = false;
     for (u32 i = 0; i < max_len; ++i) {
         const bool on = i < len;
-        // the next two bytes, asked for before the search
+        // the next two bytes, asked for before the search (never past the compressed buffer)
         const u8* ra = s + rp;
-        if (ra + 2 > comp_end) ra = comp_end - 2;
-        const u32 b0 = live && comp_size >= 2 ? ra[0] : 0u, b1 = live && comp_size >= 2 ? ra[1] : 0u;
+        const u32 b0 = live && ra < comp_end ? ra[0] : 0u, b1 = live && ra + 1 < comp_end ? ra[1] : 0u;
         const u32 slot_ = x & 16383u; // cppans.h:313-316
         u32 sym = first[on ? (slot_ >> 8) : 0u];
         // the octet tests candidates sym + j: the symbol is the first whose upper bound lies above the slot
@@ -446,4 +445,6 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_rans1_k(const u8* __restri
         }
     }
     if (live && j == 0 && ran_dry) rcx_flag(status, RCX_ST_CORRUPT, blk);
+    // the single-stream call wants what rANS::decode returns: the payload bytes consumed (cppans.h:562)
+    if (track && live && j == 0 && blk == 0) track[0] = (u32)(rp - RCX_RANS_HEADER);
 }

@@ -64,15 +64,19 @@ struct Result
     u32 requestSize_;
 };
 
-// One rcx context per thread, created on first use on device RCX_DEVICE (default 0).
+// One rcx context per thread, created on first use on device RCX_DEVICE (default 0), destroyed with the thread.
 inline rcx_ctx* facade_context()
 {
-    static thread_local rcx_ctx* ctx = nullptr;
-    if (!ctx) {
+    struct Holder {
+        rcx_ctx* ctx = nullptr;
+        ~Holder() { rcx_ctx_destroy(ctx); }
+    };
+    static thread_local Holder h;
+    if (!h.ctx) {
         const char* dev = getenv("RCX_DEVICE");
-        if (rcx_ctx_create(dev ? atoi(dev) : 0, &ctx) != RCX_OK) ctx = nullptr; // no CPU fallback: callers see Status_Error
+        if (rcx_ctx_create(dev ? atoi(dev) : 0, &h.ctx) != RCX_OK) h.ctx = nullptr; // no CPU fallback: callers see Status_Error
     }
-    return ctx;
+    return h.ctx;
 }
 
 //--- IStream (cpprcoder.h:130-166)

@@ -7,6 +7,7 @@
 //   facade_test dec  <in> <out> <sink_capacity> <piece>
 //   facade_test senc|sdec <in> <out> <sink_capacity>       static RangeEncoder<>::encode / decode
 //   facade_test blocks <in> <out> <block>                  BlockCoder round trip; out = compacted streams
+//   facade_test renc|rdec <in> <out> <size> <simd>         cppans::rANS::encode(_simd) / decode(_simd), test/main.cpp:384-387
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -14,6 +15,7 @@
 #include <iterator>
 #include <vector>
 
+#include "cpprcoder_amd/cppans.h"
 #include "cpprcoder_amd/cpprcoder.h"
 
 static std::vector<cpprcoder::u8> slurp(const char* path)
@@ -87,6 +89,25 @@ int main(int argc, char** argv)
                                            : coder.decode(sink, static_cast<u32>(in.size()), in.data());
         dump(argv[3], sink.get(), static_cast<size_t>(sink.size()));
         printf("%d 0 %d %d\n", ok ? 1 : 0, sink.size(), sink.capacity());
+        return 0;
+    }
+    if (!strcmp(argv[1], "renc")) { // the stream is the last `size` bytes of the destination (test/main.cpp:384-386)
+        const bool simd = atoi(argv[5]) != 0;
+        const cppans::u64 cap = atoi(argv[4]) > 0 ? static_cast<cppans::u64>(atoi(argv[4])) : cppans::rANS::calc_encoded_size(static_cast<u32>(in.size()));
+        std::vector<u8> dst(static_cast<size_t>(cap));
+        const u32 size = simd ? cppans::rANS::encode_simd(static_cast<u32>(cap), dst.data(), static_cast<u32>(in.size()), in.data())
+                              : cppans::rANS::encode(static_cast<u32>(cap), dst.data(), static_cast<u32>(in.size()), in.data());
+        dump(argv[3], dst.data() + cap - size, size);
+        printf("%u %llu\n", size, static_cast<unsigned long long>(cap));
+        return 0;
+    }
+    if (!strcmp(argv[1], "rdec")) {
+        const bool simd = atoi(argv[5]) != 0;
+        std::vector<u8> dst(static_cast<size_t>(atoi(argv[4])));
+        const u32 ret = simd ? cppans::rANS::decode_simd(static_cast<u32>(dst.size()), dst.data(), static_cast<u32>(in.size()), in.data())
+                             : cppans::rANS::decode(static_cast<u32>(dst.size()), dst.data(), static_cast<u32>(in.size()), in.data());
+        dump(argv[3], dst.data(), dst.size());
+        printf("%u %zu\n", ret, dst.size());
         return 0;
     }
     if (!strcmp(argv[1], "blocks")) {

@@ -99,3 +99,25 @@ def test_facade_static_range_encoder(exe, tmp_path, oracle):
         ok_ref, ref, size_ref = oracle.static_decode(piece, cap)
         (ok, _, size, _), out = run(exe, tmp_path, "sdec", piece, cap)
         assert (bool(ok), size) == (ok_ref, size_ref) and out[: len(ref)] == ref, (len(piece), cap)
+
+
+def test_facade_rans(exe, tmp_path, oracle):
+    """cppans::rANS::encode / decode / encode_simd / decode_simd (cppans.h:497-649) through include/cpprcoder_amd/cppans.h:
+    same bytes at the END of the destination, same return values (decode: payload bytes consumed, decode_simd: n)."""
+    files = workloads.canterbury_files()
+    cases = [b"hello world", bytes(range(256)), b"A" * 5000, workloads.zipf(30000, 2).tobytes(), files["fields.c"], b"xyz"]
+    for v in cases:
+        n = len(v)
+        for simd in (0, 1):
+            if simd and n < 16:
+                continue  # the reference's own calc_encoded_size is too small for encode_simd below 16 symbols
+            ref = oracle.rans_encode(v, bool(simd))
+            (size, cap), out = run(exe, tmp_path, "renc", v, 0, simd)
+            assert size == len(ref) and cap == 2 * n + 1032 and out == ref, (n, simd)
+            (ret, _), back = run(exe, tmp_path, "rdec", ref, n, simd)
+            assert back == v and ret == (n if simd else len(ref) - 1032), (n, simd)
+            (ret, _), _ = run(exe, tmp_path, "rdec", ref, n - 1, simd)  # destination too small: 0 (cppans.h:541, :618)
+            assert ret == 0
+            small = 1100 if not simd else 1130
+            (size, cap), out = run(exe, tmp_path, "renc", v, small, simd)  # a stream that does not fit: 0 (cppans.h:522, :599)
+            assert size == (len(ref) if len(ref) <= small else 0)
