@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64) void rcx_enc_adaptive_k(const u8* __restrict__ 
     const u64 at = live ? blk * (u64)block : 0;
     const u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
 
-    Tree tree{lds + lane};
+    Tree tree{reinterpret_cast<u32*>(lds) + (RCX_TREE_PLANAR ? 1 : 4) * lane};
     tree.reset();
     DivEntry* stage = reinterpret_cast<DivEntry*>(lds + RCX_GROUPS * RCX_LANES);
 
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ 
     const u64 at = live ? blk * (u64)block : 0;
     u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
 
-    Tree tree{lds + lane};
+    Tree tree{reinterpret_cast<u32*>(lds) + (RCX_TREE_PLANAR ? 1 : 4) * lane};
     tree.reset();
     DivEntry* stage = reinterpret_cast<DivEntry*>(lds + RCX_GROUPS * RCX_LANES);
     u32* ring_col = reinterpret_cast<u32*>(lds + RCX_LDS_U4) + lane;
@@ -336,5 +336,6 @@ __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ 
 }
 
 #include "rcx_oct.hpp"
+#include "variants/rcx_variants.hpp"
 #include "rcx_static.hpp"
 #include "rcx_rans.hpp"

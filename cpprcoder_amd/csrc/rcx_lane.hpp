@@ -46,8 +46,11 @@ struct alignas(16) U4 {
 //   level 1: 16 groups (64 nodes of 4 symbols)     groups 5..20
 //   level 0: 64 groups (256 counts)                groups 21..84
 // A group is 16 bytes; groups are lane-interleaved in LDS (group g of lane l at
-// (g*RCX_LANES + l) * 16) so that a ds_read_b128 of ANY per-lane group index
-// is bank-conflict free.
+// (g*RCX_LANES + l) * 16) so that a ds_read_b128 of ANY per-lane group index is bank-conflict
+// free.  The ds_add_u32 updates then hit each bank four times (35 % of the encoder's LDS cycles
+// are such conflicts); the alternative, dword planes (RCX_TREE_PLANAR=1: conflict-free adds, two
+// ds_read2st64_b32 per group), measured SLOWER (5.80 vs 5.54 ms per GiB): the encoder's waves are
+// bound by instructions issued, not by LDS cycles, and the planar layout costs one more per read.
 // ---------------------------------------------------------------------------
 #define RCX_LANES 64
 #define RCX_G_L3 0
@@ -103,25 +106,53 @@ RCX_DEV u32 rcx_funnel_shr(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_ali
 
 RCX_DEV u32 rcx_div(u32 n, const DivEntry& k) { return (u32)(((u64)n * k.mul + k.add) >> 32) >> k.shift; }
 
-// The tree of one lane.  `base` already includes the lane offset.
+// The tree of one lane.  `col` already includes the lane offset.
+#if !defined(RCX_TREE_PLANAR)
+#define RCX_TREE_PLANAR 0 /* 1 = dword planes (conflict-free ds_add, two ds_read2st64_b32 per group); 0 = 16-byte groups */
+#endif
 struct Tree {
-    U4* base;
-    RCX_DEV U4 group(u32 g) const { return base[g * RCX_LANES]; }
-    RCX_DEV void bump(u32 g, u32 p) const { rcx_lds_inc(reinterpret_cast<u32*>(&base[g * RCX_LANES]) + p); }
+    u32* col;
+#if RCX_TREE_PLANAR
+    RCX_DEV u32* at(u32 g, u32 p) const { return col + (4 * g + p) * RCX_LANES; }
+    RCX_DEV U4 group(u32 g) const
+    {
+        const u32* a = col + 4 * g * RCX_LANES;
+        U4 v;
+        v.x = a[0];
+        v.y = a[RCX_LANES];
+        v.z = a[2 * RCX_LANES];
+        v.w = a[3 * RCX_LANES];
+        return v;
+    }
+    RCX_DEV void store(u32 g, const U4& v) const
+    {
+        u32* a = col + 4 * g * RCX_LANES;
+        a[0] = v.x;
+        a[RCX_LANES] = v.y;
+        a[2 * RCX_LANES] = v.z;
+        a[3 * RCX_LANES] = v.w;
+    }
+#else
+    // group g of lane l = the 16 bytes at dword (g * RCX_LANES + l) * 4: `col` = image + 4 * lane
+    RCX_DEV u32* at(u32 g, u32 p) const { return col + 4 * g * RCX_LANES + p; }
+    RCX_DEV U4 group(u32 g) const { return *reinterpret_cast<const U4*>(col + 4 * g * RCX_LANES); }
+    RCX_DEV void store(u32 g, const U4& v) const { *reinterpret_cast<U4*>(col + 4 * g * RCX_LANES) = v; }
+#endif
+    RCX_DEV void bump(u32 g, u32 p) const { rcx_lds_inc(at(g, p)); }
     // same effect as bump() when the caller already holds the element's current value
-    RCX_DEV void put(u32 g, u32 p, u32 value) const { (reinterpret_cast<u32*>(&base[g * RCX_LANES]))[p] = value; }
+    RCX_DEV void put(u32 g, u32 p, u32 value) const { *at(g, p) = value; }
     // cpprcoder.h:1094-1132: every count 1.
     RCX_DEV void reset() const
     {
         U4 v;
         v.x = v.y = v.z = v.w = 64;
-        base[0] = v;
+        store(RCX_G_L3, v);
         v.x = v.y = v.z = v.w = 16;
-        for (u32 g = RCX_G_L2; g < RCX_G_L1; ++g) base[g * RCX_LANES] = v;
+        for (u32 g = RCX_G_L2; g < RCX_G_L1; ++g) store(g, v);
         v.x = v.y = v.z = v.w = 4;
-        for (u32 g = RCX_G_L1; g < RCX_G_L0; ++g) base[g * RCX_LANES] = v;
+        for (u32 g = RCX_G_L1; g < RCX_G_L0; ++g) store(g, v);
         v.x = v.y = v.z = v.w = 1;
-        for (u32 g = RCX_G_L0; g < RCX_GROUPS; ++g) base[g * RCX_LANES] = v;
+        for (u32 g = RCX_G_L0; g < RCX_GROUPS; ++g) store(g, v);
     }
     // cpprcoder.h:1134-1177 without the halving: +1 on the path to the leaf.
     RCX_DEV void update(u32 c) const
@@ -149,23 +180,23 @@ struct Tree {
                     v.y = (v.y >> 1) | 1u;
                     v.z = (v.z >> 1) | 1u;
                     v.w = (v.w >> 1) | 1u;
-                    base[g * RCX_LANES] = v;
+                    store(g, v);
                     sum1[q1] = v.x + v.y + v.z + v.w;
                 }
                 n1.x = sum1[0];
                 n1.y = sum1[1];
                 n1.z = sum1[2];
                 n1.w = sum1[3];
-                base[(RCX_G_L1 + 4 * q3 + q2) * RCX_LANES] = n1;
+                store(RCX_G_L1 + 4 * q3 + q2, n1);
                 sum2[q2] = sum1[0] + sum1[1] + sum1[2] + sum1[3];
             }
             n2.x = sum2[0];
             n2.y = sum2[1];
             n2.z = sum2[2];
             n2.w = sum2[3];
-            base[(RCX_G_L2 + q3) * RCX_LANES] = n2;
+            store(RCX_G_L2 + q3, n2);
             const u32 s3 = sum2[0] + sum2[1] + sum2[2] + sum2[3];
-            reinterpret_cast<u32*>(&base[RCX_G_L3 * RCX_LANES])[q3] = s3;
+            put(RCX_G_L3, q3, s3);
             total += s3;
         }
         return total;

@@ -1,32 +1,10 @@
-// rcx_oct.hpp -- 8 lanes per block ("octet") adaptive coder kernels for gfx950.
-//
-// Why 8 lanes per block.  A block is one serial chain per symbol, so 1 GiB of 64 KiB blocks
-// offers only 16384 chains.  With one lane per block that is 256 waves -- one per CU, three
-// of four SIMDs idle, and every LDS/VMEM wait exposed (measured: 39 % / 58 % of the encode /
-// decode wave cycles are waits).  With 8 lanes per block it is 2048 waves = 2 per SIMD: the
-// partner wave covers the waits, and the 8 lanes split the model work:
-//   * the table is a 2-level tree: 32 node sums (8 symbols each) + 256 counts;
-//     lane j owns the 4 node sums 4j..4j+3 (one ds_read_b128 at a FIXED address) and keeps
-//     B = the sum of all nodes before its group in a register;
-//   * encode: cum(c) = [lane c>>5] B + nodes before node(c) in its group
-//                    + [lanes < c&7] the leaf counts they read         -> one octet sum
-//   * decode: find() is two rounds of compares in the scaled domain (threshold * t <= low):
-//     round 1 finds the node among 32 (each lane tests its 4), round 2 the leaf among 8
-//     (each lane tests 1) -- one dependent LDS read per symbol instead of four, no second
-//     divide (cpprcoder.h:905) and low -= cum*t falls out of the descent.
-// The coder arithmetic (low/range/carry/renormalise, cpprcoder.h:703-711, :764-802,
-// :926-940) runs redundantly in all 8 lanes (SIMT makes that free); only lane 0 of the
-// octet touches global memory.  Cross-lane sums are 3 DPP steps (quad_perm, quad_perm,
-// row_half_mirror).  Results are bit-identical to the one-lane-per-block kernels.
+// rcx_oct.hpp -- the many-lane adaptive coder kernels for gfx950 that the library runs by default:
+//   rcx_dec_quad_k   decode, 4 lanes per block (16 blocks per wave)
+//   rcx_enc_mc5_k    encode, five waves per 64 blocks (model x3 / arithmetic / writer)
+// plus the cross-lane helpers they share with the rANS kernels.  The superseded kernels (8 lanes per block for both
+// directions, the four-wave encoder) stay selectable for comparison and live in variants/rcx_variants.hpp.
 #pragma once
 // included at the end of rcx_kernels.hpp (uses rcx_flag, rcx_wave_max, rcx_byte_of from there)
-
-#define RCX_OCT 8                 /* lanes per block */
-#define RCX_OCT_BLOCKS 8          /* blocks per wave */
-#define RCX_OCT_NODE_BYTES 128    /* 32 node sums */
-#define RCX_OCT_BLOCK_BYTES 1152  /* + 256 counts */
-#define RCX_OCT_LDS_BYTES (RCX_OCT_BLOCKS * RCX_OCT_BLOCK_BYTES + RCX_STAGE * 16)
-#define RCX_OCT_DEC_LDS_BYTES (RCX_OCT_LDS_BYTES + RCX_RING_DW * RCX_LANES * 4)
 
 template <int CTRL>
 __device__ __forceinline__ u32 rcx_dpp(u32 x)
@@ -56,278 +34,7 @@ __device__ __forceinline__ u32 rcx_oct_excl_scan(u32 x, u32 m1, u32 m2, u32 m4)
     return pre;
 }
 
-// The model of one block as seen by lane j of its octet.
-struct OctModel {
-    U4* nodes;   // this lane's group of 4 node sums (LDS)
-    u32* leaves; // the block's 256 counts (LDS)
-    u32 before;  // sum of the node sums of groups 0..j-1
-    u32 j;
-
-    __device__ __forceinline__ void reset(u8* lds_block, u32 lane_in_oct)
-    {
-        j = lane_in_oct;
-        nodes = reinterpret_cast<U4*>(lds_block) + j;
-        leaves = reinterpret_cast<u32*>(lds_block + RCX_OCT_NODE_BYTES);
-        U4 v;
-        v.x = v.y = v.z = v.w = 8; // cpprcoder.h:1094-1132: every count 1
-        *nodes = v;
-        U4 one;
-        one.x = one.y = one.z = one.w = 1;
-        U4* l4 = reinterpret_cast<U4*>(leaves);
-#pragma unroll
-        for (u32 q = 0; q < 8; ++q) l4[q * 8 + j] = one;
-        before = 32u * j;
-    }
-    // cpprcoder.h:1134-1177 (+1; the halving cannot trigger below 2^24 symbols)
-    __device__ __forceinline__ void update(u32 node, u32 leaf_lane)
-    {
-        const u32 grp = node >> 2;
-        rcx_lds_add(&leaves[node * 8 + j], j == leaf_lane ? 1u : 0u);
-        rcx_lds_add(reinterpret_cast<u32*>(nodes) + (node & 3), j == grp ? 1u : 0u);
-        before += j > grp ? 1u : 0u;
-    }
-};
-
-// ===========================================================================
-// Encode, pass 1 (8 lanes per block, 8 blocks per wave, one wave per workgroup)
-// ===========================================================================
-__global__ __launch_bounds__(64) void rcx_enc_oct_k(const u8* __restrict__ src, u64 n, u32 block, u64 nblocks,
-                                                    u8* __restrict__ slots, u64 slot, u32* __restrict__ sizes,
-                                                    const DivEntry* __restrict__ divtab, u32* status)
-{
-    __shared__ __attribute__((aligned(16))) u8 lds[RCX_OCT_LDS_BYTES];
-    const u32 lane = threadIdx.x;
-    const u32 j = lane & 7u, oct = lane >> 3;
-    const u64 blk = (u64)blockIdx.x * RCX_OCT_BLOCKS + oct;
-    const bool live = blk < nblocks;
-    const u64 at = live ? blk * (u64)block : 0;
-    const u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
-
-    OctModel model;
-    model.reset(lds + oct * RCX_OCT_BLOCK_BYTES, j);
-    DivEntry* stage = reinterpret_cast<DivEntry*>(lds + RCX_OCT_BLOCKS * RCX_OCT_BLOCK_BYTES);
-
-    EncLane enc;
-    u8* wave_slots = slots + (u64)blockIdx.x * RCX_OCT_BLOCKS * slot;
-    if (live) {
-        enc.begin(wave_slots, oct * (u32)slot, (u32)slot, len); // all 8 lanes write the same 4 header bytes
-    } else {
-        enc.idle(wave_slots);
-    }
-    enc.leader = live && j == 0;
-
-    const u32 maxlen = rcx_wave_max(len);
-    const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
-    const u8* in = src + at;
-
-#define RCX_OCT_ENC_SYMBOL(SYM, K)                                                        \
-    {                                                                                     \
-        const u32 c_ = (SYM);                                                             \
-        const u32 node_ = c_ >> 3, grp_ = c_ >> 5, lp_ = c_ & 7u;                         \
-        const U4 g_ = *model.nodes;                                                       \
-        const u32 fj_ = model.leaves[node_ * 8 + j];                                      \
-        u32 part_ = (j == grp_) ? model.before + rcx_pre4(g_, node_ & 3u) : 0u;          \
-        part_ += (j < lp_) ? fj_ : 0u;                                                    \
-        const u32 cum_ = rcx_oct_sum(part_);                                              \
-        const u32 f_ = rcx_oct_sum(j == lp_ ? fj_ : 0u);                                  \
-        enc.code(cum_, f_, (K));                                                          \
-        model.update(node_, lp_);                                                         \
-    }
-
-    DivEntry ahead = divtab[lane];
-    if (full) {
-        U4 cur = *reinterpret_cast<const U4*>(in);
-        for (u32 i0 = 0; i0 < maxlen; i0 += RCX_STAGE) {
-            stage[lane] = ahead;
-            ahead = divtab[i0 + RCX_STAGE + lane];
-            const u32 jend = (maxlen - i0) < RCX_STAGE ? (maxlen - i0) : RCX_STAGE;
-            for (u32 j0 = 0; j0 < jend; j0 += 16) {
-                const u32 i = i0 + j0;
-                U4 nxt = cur;
-                if (i + 16 < maxlen) nxt = *reinterpret_cast<const U4*>(in + i + 16);
-#pragma unroll
-                for (u32 s = 0; s < 16; ++s) RCX_OCT_ENC_SYMBOL(rcx_byte_of(cur, s), stage[j0 + s]);
-                cur = nxt;
-            }
-        }
-    } else {
-        for (u32 i0 = 0; i0 < maxlen; i0 += RCX_STAGE) {
-            stage[lane] = ahead;
-            ahead = divtab[i0 + RCX_STAGE + lane];
-            const u32 jend = (maxlen - i0) < RCX_STAGE ? (maxlen - i0) : RCX_STAGE;
-            for (u32 s = 0; s < jend; ++s) {
-                const u32 i = i0 + s;
-                const DivEntry k = stage[s];
-                if (i < len) RCX_OCT_ENC_SYMBOL(in[i], k); // len is the same in all 8 lanes of an octet
-            }
-        }
-    }
-#undef RCX_OCT_ENC_SYMBOL
-
-    const u32 bytes = enc.finish();
-    if (enc.leader) {
-        sizes[blk] = enc.overflow ? (u32)slot : bytes;
-        if (enc.overflow) rcx_flag(status, RCX_ST_CAPACITY, blk);
-    }
-}
-
-// ===========================================================================
-// Decode (8 lanes per block)
-// ===========================================================================
-// A workgroup is WAVES independent waves (no barrier between them).  With few blocks, 8 waves per workgroup
-// land two on each SIMD of one CU, which single-wave workgroups do not guarantee (measured: 20 % of the
-// kernel time); with many blocks single-wave workgroups pack more waves onto a CU.
-#define RCX_OCT_DEC_WAVES 8
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void rcx_dec_oct_k(const u8* __restrict__ comp, u64 comp_size, const u64* __restrict__ offsets,
-                                                            u64 nblocks, u32 block, u64 n, u8* __restrict__ dst,
-                                                            const DivEntry* __restrict__ divtab, u32* status)
-{
-    __shared__ __attribute__((aligned(16))) u8 lds_all[WAVES * RCX_OCT_DEC_LDS_BYTES];
-    const u32 lane = threadIdx.x & 63u;
-    const u32 wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    u8* lds = lds_all + wave_in_wg * RCX_OCT_DEC_LDS_BYTES;
-    const u32 j = lane & 7u, oct = lane >> 3;
-    const u64 blk = ((u64)blockIdx.x * WAVES + wave_in_wg) * RCX_OCT_BLOCKS + oct;
-    bool live = blk < nblocks;
-    const u64 at = live ? blk * (u64)block : 0;
-    u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
-
-    OctModel model;
-    model.reset(lds + oct * RCX_OCT_BLOCK_BYTES, j);
-    DivEntry* stage = reinterpret_cast<DivEntry*>(lds + RCX_OCT_BLOCKS * RCX_OCT_BLOCK_BYTES);
-    // every lane keeps its own copy of the octet's input ring (8 identical columns: no cross-lane ordering needed)
-    u32* ring_col = reinterpret_cast<u32*>(lds + RCX_OCT_LDS_BYTES) + lane;
-    const u32 m1 = (j & 1u) ? ~0u : 0u, m2 = (j & 2u) ? ~0u : 0u, m4 = (j & 4u) ? ~0u : 0u;
-
-    DecLane dec;
-    u64 stream_len = 0;
-    if (live) {
-        const u64 s0 = offsets[blk], s1 = offsets[blk + 1];
-        stream_len = s1 - s0;
-        if (s1 < s0 || s1 > comp_size || stream_len < 9) {
-            if (j == 0) rcx_flag(status, RCX_ST_CORRUPT, blk);
-            live = false;
-            len = 0;
-        } else {
-            const u32 declared = dec.begin(comp + s0, comp + s1, ring_col);
-            if (declared != len) {
-                if (j == 0) rcx_flag(status, RCX_ST_CORRUPT, blk);
-                live = false;
-                len = 0;
-            }
-        }
-    }
-    if (!live) dec.idle(comp, ring_col);
-
-    const u32 maxlen = rcx_wave_max(len);
-    const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
-    u8* out = dst + at;
-    const bool leader = live && j == 0;
-
-    // One symbol.  All comparisons are in the scaled domain: with t = range/total the reference's
-    // "cum(c) <= low/t < cum(c+1)" (cpprcoder.h:905, :1220-1242) is "cum(c)*t <= low < cum(c+1)*t",
-    // every product is <= total*t <= range < 2^32, and low - cum(c)*t (cpprcoder.h:906) is what
-    // is left when the descent ends.
-#define RCX_OCT_DEC_SYMBOL(K, SYM)                                                                         \
-    {                                                                                                      \
-        dec.pull();                                                                                        \
-        const DivEntry k_ = (K);                                                                           \
-        const u32 t_ = rcx_div(dec.range, k_);                                                             \
-        const u32 top_ = rcx_mul24(k_.total, t_);                                                          \
-        const U4 g_ = *model.nodes;                                                                        \
-        /* round 1: which of the 32 nodes */                                                               \
-        const u32 d_ = dec.low - rcx_mul24(model.before, t_);                                              \
-        const u32 s2_ = g_.x + g_.y, s3_ = s2_ + g_.z, s4_ = s3_ + g_.w;                                   \
-        const u32 a_ = rcx_mul24(g_.x, t_), b_ = rcx_mul24(s2_, t_), c_ = rcx_mul24(s3_, t_);              \
-        const u32 e_ = rcx_mul24(s4_, t_);                                                                 \
-        u32 p_ = 0, base_ = 0;                                                                             \
-        if (d_ >= a_) { p_ = 1; base_ = a_; }                                                              \
-        if (d_ >= b_) { p_ = 2; base_ = b_; }                                                              \
-        if (d_ >= c_) { p_ = 3; base_ = c_; }                                                              \
-        const bool own1_ = d_ < e_;                                                                        \
-        const u32 node_ = rcx_oct_sum(own1_ ? 4u * j + p_ : 0u);                                           \
-        const u32 rem_ = rcx_oct_sum(own1_ ? d_ - base_ : 0u);                                             \
-        /* round 2: which of the node's 8 symbols */                                                       \
-        const u32 fj_ = model.leaves[node_ * 8 + j];                                                       \
-        const u32 ex_ = rcx_oct_excl_scan(fj_, m1, m2, m4);                                                \
-        const u32 w_ = rcx_mul24(fj_, t_);                                                                 \
-        const u32 d2_ = rem_ - rcx_mul24(ex_, t_);                                                         \
-        const bool own2_ = d2_ < w_;                                                                       \
-        u32 low_ = rcx_oct_sum(own2_ ? d2_ : 0u);                                                          \
-        const u32 range_ = rcx_oct_sum(own2_ ? w_ : 0u);                                                   \
-        const u32 lp_ = rcx_oct_sum(own2_ ? j : 0u);                                                       \
-        /* target >= total: the reference's find() falls through to code 0 / count = total */              \
-        if (dec.low >= top_) low_ = dec.low - top_;                                                        \
-        dec.low = low_;                                                                                    \
-        dec.range = range_;                                                                                \
-        model.update(node_, lp_);                                                                          \
-        (SYM) = node_ * 8 + lp_;                                                                           \
-    }
-
-    DivEntry ahead = divtab[lane];
-    if (full) {
-        for (u32 i0 = 0; i0 < maxlen; i0 += RCX_STAGE) {
-            stage[lane] = ahead;
-            ahead = divtab[i0 + RCX_STAGE + lane];
-            const u32 jend = (maxlen - i0) < RCX_STAGE ? (maxlen - i0) : RCX_STAGE;
-            for (u32 j0 = 0; j0 < jend; j0 += 16) {
-                const u32 i = i0 + j0;
-                u32 word[4] = {0, 0, 0, 0};
-                dec.topup();
-                DivEntry k_next = stage[j0];
-#pragma unroll
-                for (u32 s = 0; s < 16; ++s) {
-                    u32 sym;
-                    const DivEntry kk = k_next;
-                    if (s + 1 < 16) k_next = stage[j0 + s + 1];
-                    RCX_OCT_DEC_SYMBOL(kk, sym);
-                    word[s >> 2] |= sym << (8 * (s & 3));
-                }
-                if (leader) {
-                    U4 o;
-                    o.x = word[0];
-                    o.y = word[1];
-                    o.z = word[2];
-                    o.w = word[3];
-                    *reinterpret_cast<U4*>(out + i) = o;
-                }
-            }
-        }
-    } else {
-        for (u32 i0 = 0; i0 < maxlen; i0 += RCX_STAGE) {
-            stage[lane] = ahead;
-            ahead = divtab[i0 + RCX_STAGE + lane];
-            const u32 jend = (maxlen - i0) < RCX_STAGE ? (maxlen - i0) : RCX_STAGE;
-            for (u32 s = 0; s < jend; ++s) {
-                const u32 i = i0 + s;
-                const DivEntry k = stage[s];
-                if ((s & 15u) == 0) dec.topup();
-                if (i < len) {
-                    u32 sym;
-                    RCX_OCT_DEC_SYMBOL(k, sym);
-                    if (leader) out[i] = (u8)sym;
-                }
-            }
-        }
-    }
-#undef RCX_OCT_DEC_SYMBOL
-    if (leader && dec.taken() > stream_len) rcx_flag(status, RCX_ST_CORRUPT, blk);
-}
-
-// ===========================================================================
-// Encode, pass 1, model/coder split ("MC"): the encoder's model side does not depend on the
-// coder state -- cum(c_i) and f(c_i) are functions of the input prefix alone
-// (cpprcoder.h:706-712) -- so one workgroup = 64 blocks runs as a 4-wave software pipeline:
-//   wave 1  model, tree levels 3+2: partial cum, its ds_add updates
-//   wave 2  model, tree level 1:    partial cum, its ds_add update
-//   wave 3  model, leaf level:      partial cum + f, its ds_add update
-//   wave 0  coder: divide / multiply / carry / renormalise / emit (cpprcoder.h:703-711, :764-802)
-// The model waves run one 16-symbol chunk ahead and hand {cumA, cumB, cumC, f} over through a
-// double-buffered LDS ring; one s_barrier per chunk.  Every instruction still serves 64 blocks
-// (one lane per block), the four instruction streams run on the four SIMDs of the CU at once,
-// and the time per symbol is the coder wave's alone.  Bytes are identical to the other kernels.
-// ===========================================================================
+// The multi-wave encoders: 16 symbols per pipeline step, double-buffered rings between the waves
 #define RCX_MC_CHUNK 16
 #define RCX_MC_THREADS 256
 #define RCX_MC_RING_U4 (2 * RCX_MC_CHUNK * RCX_LANES)
@@ -341,210 +48,10 @@ __device__ __forceinline__ void rcx_lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// The chunk loop of rcx_enc_mc_k.  FULL: every lane has a whole block and 16-byte aligned input,
-// so no per-symbol length test is needed anywhere.
-#if defined(RCX_STAMP)
+#if defined(RCX_STAMP) /* diagnostic build only (tools/diag/stamp_encode.py) */
 static __device__ unsigned long long rcx_stamp_out[16];
 #define rcx_stamp_wait stamp_wait_
 #endif
-template <bool FULL>
-__device__ __forceinline__ void rcx_mc_pipeline(u32 wave, u32 lane, u32 len, u32 nchunks, const u8* in,
-                                                const DivEntry* __restrict__ divtab, const Tree& tree, DivEntry* stage,
-                                                U4* ring, EncLane& enc, DivEntry& ahead)
-{
-#if defined(RCX_STAMP)
-    unsigned long long stamp_wait_ = 0;
-    const unsigned long long stamp_begin_ = __builtin_amdgcn_s_memtime();
-#endif
-    // model waves: the input piece of the next chunk is loaded while this one is processed
-    U4 piece_ahead;
-    piece_ahead.x = piece_ahead.y = piece_ahead.z = piece_ahead.w = 0;
-    if (FULL && wave != 0 && nchunks > 0) piece_ahead = *reinterpret_cast<const U4*>(in);
-    for (u32 k = 0; k <= nchunks; ++k) {
-        if (wave == 0) {
-            // ---- coder: chunk k-1 ----
-            if (k >= 1) {
-                const u32 i0 = (k - 1) * RCX_MC_CHUNK;
-                if ((i0 % RCX_STAGE) == 0) { // the next 64 divisors, loaded one stage ahead
-                    stage[lane] = ahead;
-                    ahead = divtab[i0 + RCX_STAGE + lane];
-                }
-                const U4* rs = ring + ((k - 1) & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
-                const DivEntry* st = stage + (i0 % RCX_STAGE);
-                // entry and divisor of the next symbol are fetched before the current one is coded,
-                // so their LDS latency hides behind the coder arithmetic
-                U4 e_next = rs[0];
-                DivEntry k_next = st[0];
-#pragma unroll
-                for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
-                    const U4 e = e_next;
-                    const DivEntry kk = k_next;
-                    if (s + 1 < RCX_MC_CHUNK) {
-                        e_next = rs[(s + 1) * RCX_LANES];
-                        k_next = st[s + 1];
-                    }
-                    if (FULL || i0 + s < len) enc.code(e.x + e.y + e.z, e.w, kk);
-                }
-            }
-        } else if (k < nchunks) {
-            // ---- model: chunk k ----
-            const u32 i0 = k * RCX_MC_CHUNK;
-            U4* ws = ring + (k & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
-            U4 piece;
-            if (FULL) {
-                piece = piece_ahead;
-                if (k + 1 < nchunks) piece_ahead = *reinterpret_cast<const U4*>(in + i0 + RCX_MC_CHUNK);
-            } else {
-                u32 w[4] = {0, 0, 0, 0};
-                for (u32 s = 0; s < RCX_MC_CHUNK; ++s)
-                    if (i0 + s < len) w[s >> 2] |= (u32)in[i0 + s] << (8 * (s & 3));
-                piece.x = w[0];
-                piece.y = w[1];
-                piece.z = w[2];
-                piece.w = w[3];
-            }
-            // Software pipeline, one symbol deep: the reads AND the ds_add updates of symbol s+1 are
-            // issued before the sums of symbol s are formed.  LDS executes a wave's operations in
-            // order, so the reads of s+1 still see the updates of s, and their latency hides
-            // behind the arithmetic of s (the updates need only the symbol, not the read data).
-            if (wave == 1) {
-                u32 c = rcx_byte_of(piece, 0);
-                bool on = FULL || i0 < len;
-                U4 g3 = tree.group(RCX_G_L3), g2 = tree.group(RCX_G_L2 + (c >> 6));
-                if (on) {
-                    tree.bump(RCX_G_L3, c >> 6);
-                    tree.bump(RCX_G_L2 + (c >> 6), (c >> 4) & 3);
-                }
-#pragma unroll
-                for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
-                    const u32 cc = c;
-                    const bool onc = on;
-                    const U4 h3 = g3, h2 = g2;
-                    if (s + 1 < RCX_MC_CHUNK) {
-                        c = rcx_byte_of(piece, s + 1);
-                        on = FULL || i0 + s + 1 < len;
-                        g3 = tree.group(RCX_G_L3);
-                        g2 = tree.group(RCX_G_L2 + (c >> 6));
-                        if (on) {
-                            tree.bump(RCX_G_L3, c >> 6);
-                            tree.bump(RCX_G_L2 + (c >> 6), (c >> 4) & 3);
-                        }
-                    }
-                    if (onc) reinterpret_cast<u32*>(&ws[s * RCX_LANES])[0] = rcx_pre4(h3, cc >> 6) + rcx_pre4(h2, (cc >> 4) & 3);
-                }
-            } else if (wave == 2) {
-                u32 c = rcx_byte_of(piece, 0);
-                bool on = FULL || i0 < len;
-                U4 g1 = tree.group(RCX_G_L1 + (c >> 4));
-                if (on) tree.bump(RCX_G_L1 + (c >> 4), (c >> 2) & 3);
-#pragma unroll
-                for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
-                    const u32 cc = c;
-                    const bool onc = on;
-                    const U4 h1 = g1;
-                    if (s + 1 < RCX_MC_CHUNK) {
-                        c = rcx_byte_of(piece, s + 1);
-                        on = FULL || i0 + s + 1 < len;
-                        g1 = tree.group(RCX_G_L1 + (c >> 4));
-                        if (on) tree.bump(RCX_G_L1 + (c >> 4), (c >> 2) & 3);
-                    }
-                    if (onc) reinterpret_cast<u32*>(&ws[s * RCX_LANES])[1] = rcx_pre4(h1, (cc >> 2) & 3);
-                }
-            } else {
-                u32 c = rcx_byte_of(piece, 0);
-                bool on = FULL || i0 < len;
-                U4 g0 = tree.group(RCX_G_L0 + (c >> 2));
-                if (on) tree.bump(RCX_G_L0 + (c >> 2), c & 3);
-#pragma unroll
-                for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
-                    const u32 cc = c;
-                    const bool onc = on;
-                    const U4 h0 = g0;
-                    if (s + 1 < RCX_MC_CHUNK) {
-                        c = rcx_byte_of(piece, s + 1);
-                        on = FULL || i0 + s + 1 < len;
-                        g0 = tree.group(RCX_G_L0 + (c >> 2));
-                        if (on) tree.bump(RCX_G_L0 + (c >> 2), c & 3);
-                    }
-                    if (onc) {
-                        u32* e = reinterpret_cast<u32*>(&ws[s * RCX_LANES]);
-                        e[2] = rcx_pre4(h0, cc & 3);
-                        e[3] = rcx_sel4(h0, cc & 3);
-                    }
-                }
-            }
-        }
-#if defined(RCX_STAMP) /* diagnostic build only: where do the waves of workgroup 0 wait? */
-        const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
-        rcx_lds_barrier();
-        const unsigned long long t1_ = __builtin_amdgcn_s_memtime();
-        rcx_stamp_wait += t1_ - t0_;
-#else
-        rcx_lds_barrier();
-#endif
-    }
-#if defined(RCX_STAMP)
-    if (blockIdx.x == 7 && lane == 0) {
-        rcx_stamp_out[wave * 2] = __builtin_amdgcn_s_memtime() - stamp_begin_;
-        rcx_stamp_out[wave * 2 + 1] = stamp_wait_;
-    }
-#endif
-}
-
-__global__ __launch_bounds__(RCX_MC_THREADS) void rcx_enc_mc_k(const u8* __restrict__ src, u64 n, u32 block, u64 nblocks,
-                                                              u8* __restrict__ slots, u64 slot, u32* __restrict__ sizes,
-                                                              const DivEntry* __restrict__ divtab, u32* status)
-{
-    __shared__ U4 lds[RCX_MC_LDS_U4];
-    const u32 lane = threadIdx.x & 63u;
-    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const u64 blk = (u64)blockIdx.x * RCX_LANES + lane;
-    const bool live = blk < nblocks;
-    const u64 at = live ? blk * (u64)block : 0;
-    const u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
-
-    Tree tree{lds + lane};
-    DivEntry* stage = reinterpret_cast<DivEntry*>(lds + RCX_GROUPS * RCX_LANES);
-    U4* ring = lds + RCX_LDS_U4;
-
-    const u32 maxlen = rcx_wave_max(len); // the four waves hold the same 64 blocks: same value in each
-    const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
-    const u8* in = src + at;
-    const u32 nchunks = (maxlen + RCX_MC_CHUNK - 1) / RCX_MC_CHUNK;
-
-    EncLane enc;
-    DivEntry ahead;
-    ahead.mul = ahead.add = ahead.shift = ahead.total = 0;
-    U4 v;
-    if (wave == 0) {
-        u8* wave_slots = slots + (u64)blockIdx.x * RCX_LANES * slot;
-        if (live) enc.begin(wave_slots, lane * (u32)slot, (u32)slot, len);
-        else enc.idle(wave_slots);
-        ahead = divtab[lane];
-    } else if (wave == 1) { // cpprcoder.h:1094-1132: every count 1
-        v.x = v.y = v.z = v.w = 64;
-        tree.base[0] = v;
-        v.x = v.y = v.z = v.w = 16;
-        for (u32 g = RCX_G_L2; g < RCX_G_L1; ++g) tree.base[g * RCX_LANES] = v;
-    } else if (wave == 2) {
-        v.x = v.y = v.z = v.w = 4;
-        for (u32 g = RCX_G_L1; g < RCX_G_L0; ++g) tree.base[g * RCX_LANES] = v;
-    } else {
-        v.x = v.y = v.z = v.w = 1;
-        for (u32 g = RCX_G_L0; g < RCX_GROUPS; ++g) tree.base[g * RCX_LANES] = v;
-    }
-    rcx_lds_barrier();
-
-    if (full) rcx_mc_pipeline<true>(wave, lane, len, nchunks, in, divtab, tree, stage, ring, enc, ahead);
-    else rcx_mc_pipeline<false>(wave, lane, len, nchunks, in, divtab, tree, stage, ring, enc, ahead);
-
-    if (wave == 0 && live) {
-        const u32 bytes = enc.finish();
-        sizes[blk] = enc.overflow ? (u32)slot : bytes;
-        if (enc.overflow) rcx_flag(status, RCX_ST_CAPACITY, blk);
-    }
-}
-
 // ===========================================================================
 // Decode, 4 lanes per block ("quad"): 16 blocks per wave, 1024 waves for 1 GiB of 64 KiB
 // blocks = one wave per SIMD.  A lone wave issues one instruction -- vector, scalar, s_nop or
@@ -820,16 +327,10 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
     // LDS and global accesses stay with the compiler (and its s_waitcnt placement).
     const u32 T0p3 = T0 + 3;
     const u32 leaves_lds = (u32)reinterpret_cast<uintptr_t>(leaves); // low half of a flat LDS address = the LDS offset
-#if !defined(RCX_EXP_GAP_PAD) /* experiments (tools/diag): extra idempotent instructions behind the dependent LDS read */
-#define RCX_EXP_GAP_PAD
-#endif
 #if defined(RCX_STAMP_DEC) /* diagnostic build only (tools/diag/stamp_quad.py): where does one symbol's time go? */
 #define RCX_QUAD_STAMP(i) if (stamp_now_) stamp_t_[stamp_at_ + (i)] = __builtin_amdgcn_s_memtime();
 #else
 #define RCX_QUAD_STAMP(i)
-#endif
-#if !defined(RCX_EXP_LDS_ADD)
-#define RCX_EXP_LDS_ADD(p, v) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)
 #endif
 #define RCX_QP1 "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
 #define RCX_QP2 "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -883,7 +384,6 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
                      "v_cmp_lt_u32_e64 %[c2], %[n], %[t2]\n\t"                                             \
                      "v_cmp_lt_u32_e64 %[c3], %[n], %[t3]\n\t"                                             \
                      "v_cmp_le_u32_e64 %[c4], %[n], %[t3]\n\t"                                             \
-                     RCX_EXP_GAP_PAD                                                                       \
                      "v_addc_co_u32_e64 %[u1], %[c1], 0, %[u1], %[c1]\n\t"                                 \
                      "v_addc_co_u32_e64 %[u2], %[c2], 0, %[u2], %[c2]\n\t"                                 \
                      "v_addc_co_u32_e64 %[u3], %[c3], 0, %[u3], %[c3]\n\t"                                 \
@@ -942,7 +442,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
         RCX_QUAD_STAMP(1);                                                                                 \
         in.low = lo_;   /* :906 */                                                                         \
         in.range = rg_; /* :907 */                                                                         \
-        RCX_EXP_LDS_ADD(reinterpret_cast<RcxLdsU32*>(ye_), own_); /* :916 */                                \
+        (void)__hip_atomic_fetch_add(reinterpret_cast<RcxLdsU32*>(ye_), own_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); /* :916 */ \
     }
 
     // The divisors of the next 16 symbols are converted and written to LDS at every top-up, and the 16 after
@@ -1084,6 +584,25 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
 // and such a block is marked in `redo` and encoded again by rcx_enc_adaptive_k.
 // ===========================================================================
 #define RCX_MC5_THREADS 320
+// The ring between the model waves and the arithmetic wave: four dwords per symbol and lane.  Kept as 16 contiguous
+// bytes per lane (one ds_read_b128 for the arithmetic wave; the model waves' 4-byte stores hit each bank four times)
+// or, RCX_RING_PLANAR=1, as four dword planes (conflict-free stores, two ds_read2st64_b32).
+#if !defined(RCX_RING_PLANAR)
+#define RCX_RING_PLANAR 0
+#endif
+#if !defined(RCX_MODEL_AHEAD)
+#define RCX_MODEL_AHEAD 1 /* symbols the model waves' LDS reads and updates run ahead of their sums */
+#endif
+#if !defined(RCX_ARITH_AHEAD)
+#define RCX_ARITH_AHEAD 1 /* symbols the arithmetic wave's ring and divisor reads run ahead */
+#endif
+#if RCX_RING_PLANAR
+#define RCX_RING_LANE 1
+#define RCX_RING_AT(s, f) ((4 * (s) + (f)) * RCX_LANES)
+#else
+#define RCX_RING_LANE 4
+#define RCX_RING_AT(s, f) (4 * (s) * RCX_LANES + (f))
+#endif
 #define RCX_MC5_RING2_DW (2 * RCX_MC_CHUNK * RCX_LANES)
 #define RCX_OUT_RING_WORDS 64 /* per block: 256 bytes of output waiting in LDS */
 #define RCX_OUT_MARGIN 32     /* bytes kept back from the drain */
@@ -1156,7 +675,7 @@ struct StagedWriter {
 template <bool FULL>
 __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u32 nchunks, const u8* in,
                                                  const DivEntry* __restrict__ divtab, const Tree& tree, DivEntry* stage,
-                                                 U4* ring, u32* ring2, EncLane& enc, DivEntry& ahead, StagedWriter& wr,
+                                                 u32* ring, u32* ring2, EncLane& enc, DivEntry& ahead, StagedWriter& wr,
                                                  u32* out_pos, u32& drained, u8* payload, u32 cap, bool live)
 {
     // wave roles: 0 arithmetic, 1 writer, 2 model levels 3+2, 3 model leaf level, 4 model level 1 + drain
@@ -1181,27 +700,34 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
                     reinterpret_cast<DivQ*>(stage)[lane] = q;
                     ahead = divtab[i0 + RCX_STAGE + lane];
                 }
-                const U4* rs = ring + ((k - 1) & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
+                // the model waves' answers: field f of symbol s of lane l at dword RCX_RING_AT(s, f) + RCX_RING_LANE * l
+                const u32* rs = ring + ((k - 1) & 1u) * (4 * RCX_MC_CHUNK * RCX_LANES) + RCX_RING_LANE * lane;
                 u32* ws2 = ring2 + ((k - 1) & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
                 // the chunk's divisors through one vector base register and immediate offsets (a wave-uniform
                 // address would be rebuilt in a scalar register and moved over for every read)
                 u32 st_lds = (u32)reinterpret_cast<uintptr_t>(stage + (i0 % RCX_STAGE));
                 asm volatile("" : "+v"(st_lds));
                 const RcxLdsDivQ* st = reinterpret_cast<const RcxLdsDivQ*>(st_lds);
-                U4 e_next = rs[0];
-                RcxDivQv k_next = st[0];
+                U4 eq[RCX_MC_CHUNK];
+                RcxDivQv kq[RCX_MC_CHUNK];
+#define RCX_A_ISSUE(T)                                                                                              \
+    {                                                                                                               \
+        eq[T].x = rs[RCX_RING_AT((T), 0)], eq[T].y = rs[RCX_RING_AT((T), 1)], eq[T].z = rs[RCX_RING_AT((T), 2)];    \
+        eq[T].w = rs[RCX_RING_AT((T), 3)];                                                                          \
+        kq[T] = st[T];                                                                                              \
+    }
+#pragma unroll
+                for (u32 t = 0; t < RCX_ARITH_AHEAD; ++t) RCX_A_ISSUE(t);
 #pragma unroll
                 for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
-                    const U4 e = e_next;
-                    const RcxDivQv kk = k_next;
-                    if (s + 1 < RCX_MC_CHUNK) {
-                        e_next = rs[(s + 1) * RCX_LANES];
-                        k_next = st[s + 1];
-                    }
+                    if (s + RCX_ARITH_AHEAD < RCX_MC_CHUNK) RCX_A_ISSUE(s + RCX_ARITH_AHEAD);
+                    const U4 e = eq[s];
+                    const RcxDivQv kk = kq[s];
                     u32 rec = 0; // past the end of a short block: a record that does nothing
                     if (FULL || i0 + s < len) rec = enc.arith_q(e.x + e.y + e.z, e.w, kk.x, kk.y, ((u64)kk.w << 32) | kk.z);
                     ws2[s * RCX_LANES] = rec;
                 }
+#undef RCX_A_ISSUE
             }
         } else if (wave == 1) {
             // ---- writer: chunk k-2 from ring2[(k-2)&1] ----
@@ -1240,7 +766,7 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
           if (k < nchunks) {
             // ---- model: chunk k ----
             const u32 i0 = k * RCX_MC_CHUNK;
-            U4* ws = ring + (k & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
+            u32* ws = ring + (k & 1u) * (4 * RCX_MC_CHUNK * RCX_LANES) + RCX_RING_LANE * lane;
             U4 piece;
             if (FULL) {
                 piece = piece_ahead;
@@ -1254,71 +780,67 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
                 piece.z = w[2];
                 piece.w = w[3];
             }
+            // Software pipeline, RCX_MODEL_AHEAD symbols deep: the group reads AND the ds_add updates of symbol
+            // s + AHEAD are issued before the sums of symbol s are formed.  LDS executes a wave's operations in order,
+            // so the reads of a later symbol still see the updates of the earlier ones, and their latency -- 60 cycles
+            // and more with five waves on the LDS unit, i.e. more than one symbol of a light wave -- hides behind the
+            // arithmetic of the symbols in between (the updates need only the symbol, not the read data).
+            U4 ga[RCX_MC_CHUNK], gb[RCX_MC_CHUNK]; // (indices are compile-time constants: registers)
             if (wave == 2) {
-                u32 c = rcx_byte_of(piece, 0);
-                bool on = FULL || i0 < len;
-                U4 g3 = tree.group(RCX_G_L3), g2 = tree.group(RCX_G_L2 + (c >> 6));
-                if (on) {
-                    tree.bump(RCX_G_L3, c >> 6);
-                    tree.bump(RCX_G_L2 + (c >> 6), (c >> 4) & 3);
-                }
+#define RCX_M2_ISSUE(T)                                                       \
+    {                                                                         \
+        const u32 c_ = rcx_byte_of(piece, (T));                               \
+        ga[T] = tree.group(RCX_G_L3);                                         \
+        gb[T] = tree.group(RCX_G_L2 + (c_ >> 6));                             \
+        if (FULL || i0 + (T) < len) {                                         \
+            tree.bump(RCX_G_L3, c_ >> 6);                                     \
+            tree.bump(RCX_G_L2 + (c_ >> 6), (c_ >> 4) & 3);                   \
+        }                                                                     \
+    }
+#pragma unroll
+                for (u32 t = 0; t < RCX_MODEL_AHEAD; ++t) RCX_M2_ISSUE(t);
 #pragma unroll
                 for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
-                    const u32 cc = c;
-                    const bool onc = on;
-                    const U4 h3 = g3, h2 = g2;
-                    if (s + 1 < RCX_MC_CHUNK) {
-                        c = rcx_byte_of(piece, s + 1);
-                        on = FULL || i0 + s + 1 < len;
-                        g3 = tree.group(RCX_G_L3);
-                        g2 = tree.group(RCX_G_L2 + (c >> 6));
-                        if (on) {
-                            tree.bump(RCX_G_L3, c >> 6);
-                            tree.bump(RCX_G_L2 + (c >> 6), (c >> 4) & 3);
-                        }
-                    }
-                    if (onc) reinterpret_cast<u32*>(&ws[s * RCX_LANES])[0] = rcx_pre4(h3, cc >> 6) + rcx_pre4(h2, (cc >> 4) & 3);
+                    if (s + RCX_MODEL_AHEAD < RCX_MC_CHUNK) RCX_M2_ISSUE(s + RCX_MODEL_AHEAD);
+                    const u32 cc = rcx_byte_of(piece, s);
+                    if (FULL || i0 + s < len) ws[RCX_RING_AT(s, 0)] = rcx_pre4(ga[s], cc >> 6) + rcx_pre4(gb[s], (cc >> 4) & 3);
                 }
+#undef RCX_M2_ISSUE
             } else if (wave == 4) {
-                u32 c = rcx_byte_of(piece, 0);
-                bool on = FULL || i0 < len;
-                U4 g1 = tree.group(RCX_G_L1 + (c >> 4));
-                if (on) tree.bump(RCX_G_L1 + (c >> 4), (c >> 2) & 3);
+#define RCX_M1_ISSUE(T)                                                       \
+    {                                                                         \
+        const u32 c_ = rcx_byte_of(piece, (T));                               \
+        ga[T] = tree.group(RCX_G_L1 + (c_ >> 4));                             \
+        if (FULL || i0 + (T) < len) tree.bump(RCX_G_L1 + (c_ >> 4), (c_ >> 2) & 3); \
+    }
+#pragma unroll
+                for (u32 t = 0; t < RCX_MODEL_AHEAD; ++t) RCX_M1_ISSUE(t);
 #pragma unroll
                 for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
-                    const u32 cc = c;
-                    const bool onc = on;
-                    const U4 h1 = g1;
-                    if (s + 1 < RCX_MC_CHUNK) {
-                        c = rcx_byte_of(piece, s + 1);
-                        on = FULL || i0 + s + 1 < len;
-                        g1 = tree.group(RCX_G_L1 + (c >> 4));
-                        if (on) tree.bump(RCX_G_L1 + (c >> 4), (c >> 2) & 3);
-                    }
-                    if (onc) reinterpret_cast<u32*>(&ws[s * RCX_LANES])[1] = rcx_pre4(h1, (cc >> 2) & 3);
+                    if (s + RCX_MODEL_AHEAD < RCX_MC_CHUNK) RCX_M1_ISSUE(s + RCX_MODEL_AHEAD);
+                    const u32 cc = rcx_byte_of(piece, s);
+                    if (FULL || i0 + s < len) ws[RCX_RING_AT(s, 1)] = rcx_pre4(ga[s], (cc >> 2) & 3);
                 }
+#undef RCX_M1_ISSUE
             } else {
-                u32 c = rcx_byte_of(piece, 0);
-                bool on = FULL || i0 < len;
-                U4 g0 = tree.group(RCX_G_L0 + (c >> 2));
-                if (on) tree.bump(RCX_G_L0 + (c >> 2), c & 3);
+#define RCX_M0_ISSUE(T)                                                       \
+    {                                                                         \
+        const u32 c_ = rcx_byte_of(piece, (T));                               \
+        ga[T] = tree.group(RCX_G_L0 + (c_ >> 2));                             \
+        if (FULL || i0 + (T) < len) tree.bump(RCX_G_L0 + (c_ >> 2), c_ & 3);  \
+    }
+#pragma unroll
+                for (u32 t = 0; t < RCX_MODEL_AHEAD; ++t) RCX_M0_ISSUE(t);
 #pragma unroll
                 for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
-                    const u32 cc = c;
-                    const bool onc = on;
-                    const U4 h0 = g0;
-                    if (s + 1 < RCX_MC_CHUNK) {
-                        c = rcx_byte_of(piece, s + 1);
-                        on = FULL || i0 + s + 1 < len;
-                        g0 = tree.group(RCX_G_L0 + (c >> 2));
-                        if (on) tree.bump(RCX_G_L0 + (c >> 2), c & 3);
-                    }
-                    if (onc) {
-                        u32* e = reinterpret_cast<u32*>(&ws[s * RCX_LANES]);
-                        e[2] = rcx_pre4(h0, cc & 3);
-                        e[3] = rcx_sel4(h0, cc & 3);
+                    if (s + RCX_MODEL_AHEAD < RCX_MC_CHUNK) RCX_M0_ISSUE(s + RCX_MODEL_AHEAD);
+                    const u32 cc = rcx_byte_of(piece, s);
+                    if (FULL || i0 + s < len) {
+                        ws[RCX_RING_AT(s, 2)] = rcx_pre4(ga[s], cc & 3);
+                        ws[RCX_RING_AT(s, 3)] = rcx_sel4(ga[s], cc & 3);
                     }
                 }
+#undef RCX_M0_ISSUE
             }
           }
         }
@@ -1354,9 +876,9 @@ __global__ __launch_bounds__(RCX_MC5_THREADS) void rcx_enc_mc5_k(const u8* __res
     const u64 at = live ? blk * (u64)block : 0;
     const u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
 
-    Tree tree{lds + lane};
+    Tree tree{reinterpret_cast<u32*>(lds) + (RCX_TREE_PLANAR ? 1 : 4) * lane};
     DivEntry* stage = reinterpret_cast<DivEntry*>(lds + RCX_GROUPS * RCX_LANES);
-    U4* ring = lds + RCX_LDS_U4;
+    u32* ring = reinterpret_cast<u32*>(lds + RCX_LDS_U4);
     u32* ring2 = reinterpret_cast<u32*>(lds + RCX_MC_LDS_U4);
     u32* final_low = ring2 + RCX_MC5_RING2_DW; // 64 dwords: the arithmetic wave's last low, for the writer's finish()
     u32* out_ring = final_low + RCX_LANES;     // the writer's words on their way to global memory
@@ -1385,15 +907,15 @@ __global__ __launch_bounds__(RCX_MC5_THREADS) void rcx_enc_mc5_k(const u8* __res
         out_pos[lane] = 0;
     } else if (wave == 2) { // cpprcoder.h:1094-1132: every count 1
         v.x = v.y = v.z = v.w = 64;
-        tree.base[0] = v;
+        tree.store(RCX_G_L3, v);
         v.x = v.y = v.z = v.w = 16;
-        for (u32 g = RCX_G_L2; g < RCX_G_L1; ++g) tree.base[g * RCX_LANES] = v;
+        for (u32 g = RCX_G_L2; g < RCX_G_L1; ++g) tree.store(g, v);
     } else if (wave == 4) {
         v.x = v.y = v.z = v.w = 4;
-        for (u32 g = RCX_G_L1; g < RCX_G_L0; ++g) tree.base[g * RCX_LANES] = v;
+        for (u32 g = RCX_G_L1; g < RCX_G_L0; ++g) tree.store(g, v);
     } else {
         v.x = v.y = v.z = v.w = 1;
-        for (u32 g = RCX_G_L0; g < RCX_GROUPS; ++g) tree.base[g * RCX_LANES] = v;
+        for (u32 g = RCX_G_L0; g < RCX_GROUPS; ++g) tree.store(g, v);
     }
     rcx_lds_barrier();
 

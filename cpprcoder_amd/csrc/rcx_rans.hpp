@@ -23,10 +23,9 @@
 
 // LDS of one block while encoding: cum[257] (kept for the header) | table[256] = start | freq << 16 | 64 staged input bytes
 #define RCX_RANS_ENC_LDS_DW (264 + 256 + 16)
-// ... while decoding: cum[257] as u16 (+ pad) | the symbol lookup: slot2symbol[4096] (eight-state format) or
-// first[64] = the symbol holding slot 256*k (one-state format; the octet scans on from there)
+// ... while decoding, one-state format: cum[257] as u16 (+ pad) | first[64] = the symbol holding slot 256*k (the octet
+// scans on from there); eight-state format: see rcx_dec_rans8_k
 #define RCX_RANS_DEC_CUM_BYTES 528
-#define RCX_RANS8_DEC_LDS_BYTES (RCX_RANS_DEC_CUM_BYTES + 4096)
 #define RCX_RANS1_DEC_LDS_BYTES (RCX_RANS_DEC_CUM_BYTES + 64)
 
 // Lanes of one octet talk through LDS without a barrier: a wave's LDS operations execute in order.  This keeps the
@@ -287,21 +286,40 @@ __device__ __forceinline__ bool rcx_rans_read_header(const u8* s, u64 stream_len
     return good && all_ok;
 }
 
+// ---------------------------------------------------------------------------------------------------------
 // The eight-state format: lane j is state j (cppans.h:609-649).
+//
+// What the step of a lone wave costs is its chain of dependent memory reads, so everything on that chain is in LDS
+// and as much of the machine's waves as possible are resident (2.4 KiB of LDS per block: 8 waves per CU):
+//   * symbol lookup (the reference's 16 KiB slots_ + 4 KiB slot2symbol_ per stream, cppans.h:59-63) in two reads:
+//     first[slot >> 2] = index, among the symbols that occur, of the one holding slot 4*(slot >> 2); the symbol is
+//     that one or one of the next three (4 slots hold at most 4 symbols), whose packed entries
+//     start | (freq - 1) << 12 | symbol << 24 come back as one pair of ds_read2_b32;
+//   * the word stream through a 256-byte ring per block, filled 128 bytes at a time by the octet's 16-byte loads,
+//     issued a step before they are written to LDS and seven steps before they can be needed;
+//   * the symbols through a 64-byte buffer per block: eight steps are written out as one 8-byte store per lane.
+// ---------------------------------------------------------------------------------------------------------
+#define RCX_R8_FIRST_BYTES 1024
+#define RCX_R8_TABLE_DW 260 /* at most 256 symbols occur + 3 copies of the last (the 4-entry window never leaves the table) */
+#define RCX_R8_RING_BYTES 256
+#define RCX_R8_LDS_BYTES (RCX_R8_FIRST_BYTES + 4 * RCX_R8_TABLE_DW + RCX_R8_RING_BYTES + 64)
+
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void rcx_dec_rans8_k(const u8* __restrict__ comp, u64 comp_size, const u64* __restrict__ offsets,
                                                              u64 nblocks, u32 block, u64 n, u8* __restrict__ dst, u32* status)
 {
-    __shared__ __attribute__((aligned(16))) u8 lds_all[WAVES * RCX_RANS_BLOCKS * RCX_RANS8_DEC_LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) u8 lds_all[WAVES * RCX_RANS_BLOCKS * RCX_R8_LDS_BYTES];
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const u32 j = lane & 7u, oct = lane >> 3;
     const u64 blk = ((u64)blockIdx.x * WAVES + wave) * RCX_RANS_BLOCKS + oct;
     bool live = blk < nblocks;
     const u64 at = live ? blk * (u64)block : 0;
     u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
-    u8* mine = lds_all + (wave * RCX_RANS_BLOCKS + oct) * RCX_RANS8_DEC_LDS_BYTES;
-    unsigned short* cum16 = reinterpret_cast<unsigned short*>(mine);
-    u8* slot2sym = mine + RCX_RANS_DEC_CUM_BYTES;
+    u8* mine = lds_all + (wave * RCX_RANS_BLOCKS + oct) * RCX_R8_LDS_BYTES;
+    u8* first = mine;
+    u32* table = reinterpret_cast<u32*>(mine + RCX_R8_FIRST_BYTES);
+    u8* ring = mine + RCX_R8_FIRST_BYTES + 4 * RCX_R8_TABLE_DW;
+    u8* obuf = ring + RCX_R8_RING_BYTES;
 
     const u8* s = comp;
     u64 stream_len = 0;
@@ -309,58 +327,148 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_rans8_k(const u8* __restri
         const u64 s0 = offsets[blk], s1 = offsets[blk + 1];
         stream_len = s1 - s0;
         s = comp + s0;
-        bool good = s1 >= s0 && s1 <= comp_size;
-        if (good) good = rcx_rans_read_header<12>(s, stream_len, len, cum16, j, lane, 32);
+        bool good = s1 >= s0 && s1 <= comp_size && stream_len >= RCX_RANS_HEADER + 32;
+        if (good) good = rcx_load_le32(s) == len; // cppans.h:616-620: the declared size (the layout says len)
+        // The table (cppans.h:621-626).  Lane j takes symbols 32j .. 32j+31: checks that their bounds form a scaled
+        // cumulative table (the reference trusts it and would leave its arrays), counts the symbols that occur, and
+        // -- once the octet knows how many occur before its range -- writes their packed entries and the cells of
+        // `first` whose first slot they hold.
+        u32 bounds_ok = 1, mine_count = 0;
+        if (good) {
+            u32 lo = rcx_load_le32(s + 4 + 4 * (32 * j));
+            if (j == 0 && lo != 0) bounds_ok = 0;
+            for (u32 k = 0; k < 32; ++k) {
+                const u32 hi = rcx_load_le32(s + 4 + 4 * (32 * j + k + 1));
+                if (hi < lo || hi > 4096u) bounds_ok = 0;
+                mine_count += hi > lo ? 1u : 0u;
+                lo = hi;
+            }
+            if (j == 7 && lo != 4096u) bounds_ok = 0;
+        }
+        good = good && rcx_octet_ballot(bounds_ok == 0, lane) == 0;
+        if (good) {
+            u32 rank = rcx_oct_excl_scan(mine_count, (j & 1u) ? ~0u : 0u, (j & 2u) ? ~0u : 0u, (j & 4u) ? ~0u : 0u);
+            const u32 total = rcx_oct_sum(mine_count);
+            u32 lo = rcx_load_le32(s + 4 + 4 * (32 * j));
+            u32 last_entry = 0;
+            for (u32 k = 0; k < 32; ++k) {
+                const u32 hi = rcx_load_le32(s + 4 + 4 * (32 * j + k + 1));
+                if (hi > lo) {
+                    const u32 entry = lo | ((hi - lo - 1) << 12) | ((32 * j + k) << 24);
+                    table[rank] = entry;
+                    last_entry = entry;
+                    for (u32 c = (lo + 3) >> 2; c <= (hi - 1) >> 2; ++c) first[c] = (u8)rank; // cells whose slot 4c it holds
+                    rank += 1;
+                }
+                lo = hi;
+            }
+            // three copies of the last entry behind it (written by the lane that owns it)
+            if (mine_count != 0 && rank == total) table[total] = table[total + 1] = table[total + 2] = last_entry;
+        }
         if (!good) {
             if (j == 0) rcx_flag(status, RCX_ST_CORRUPT, blk);
             live = false;
             len = 0;
         }
     }
-    // cppans.h:623-626 (initSymbols :342-351): which symbol owns each of the 4096 slots; lane j fills symbols j, j+8, ...
-    if (live) {
-        for (u32 sym = j; sym < 256; sym += 8) {
-            const u32 lo = cum16[sym], hi = cum16[sym + 1];
-            for (u32 i = lo; i < hi; ++i) slot2sym[i] = (u8)sym;
-        }
-    }
     rcx_octet_sync();
+
+    // the word stream: `origin` = the 16-byte aligned address at or below the first word; p = offset of the next word
     const u8* const comp_end = comp + comp_size;
+    const u8* const words = s + RCX_RANS_HEADER + 32;
+    const u8* const origin = words - (reinterpret_cast<uintptr_t>(words) & 15u);
+    u32 p = (u32)(words - origin);
+    u32 filled = 0; // ring holds [filled - 256, filled) of the stream (offsets from origin), as far as it was loaded
+    auto load16 = [&](u32 off) -> U4 { // lane j's piece of the 128 bytes at `off`; bytes past the buffer read as zero
+        const u8* a = origin + off + 16 * j;
+        U4 z;
+        z.x = z.y = z.z = z.w = 0;
+        if (!live || a >= comp_end) return z;
+        if (a + 16 <= comp_end) return *reinterpret_cast<const U4*>(a);
+        u32 w[4] = {0, 0, 0, 0}; // the buffer's last, partial piece
+        for (u32 k = 0; a + k < comp_end; ++k) w[k >> 2] |= (u32)a[k] << (8 * (k & 3));
+        z.x = w[0], z.y = w[1], z.z = w[2], z.w = w[3];
+        return z;
+    };
+    if (live) { // prologue: both halves
+        *reinterpret_cast<U4*>(ring + 16 * j) = load16(0);
+        *reinterpret_cast<U4*>(ring + 128 + 16 * j) = load16(128);
+    }
+    filled = 256;
+    U4 pend;
+    pend.x = pend.y = pend.z = pend.w = 0;
+    bool pending = false;
+    rcx_octet_sync();
+
+    // Streams compacted by the encoder have even sizes, so in an even-aligned buffer every 16-bit word is aligned;
+    // a stream at an odd address has its words read as two bytes (the whole wave then does).
+    const bool even = __all(!live || (reinterpret_cast<uintptr_t>(words) & 1u) == 0);
     u32 x = live ? rcx_load_le32(s + RCX_RANS_HEADER + 4 * j) : (1u << 16); // cppans.h:405-409
-    u64 wp = RCX_RANS_HEADER + 32;                                          // the next word, as a byte offset in the stream
     u8* out = dst + at;
+    const bool out8 = (reinterpret_cast<uintptr_t>(out) & 7u) == 0;
     const u32 groups = len >> 3;
     const u32 max_groups = rcx_wave_max(groups);
-    bool ran_dry = false;
     for (u32 g = 0; g < max_groups; ++g) {
         const bool on = g < groups;
-        // the j-th upcoming word, asked for before the table lookups (a read past the buffer is clamped; a read past the
-        // stream is caught below)
-        const u8* wa = s + wp + 2 * j;
-        if (wa + 2 > comp_end) wa = comp_end - 2;
-        const u32 cand = live && comp_size >= 2 ? ((u32)wa[0] | ((u32)wa[1] << 8)) : 0u;
+        // the 128 bytes asked for in the previous step go into the half of the ring that has been used up
+        if (pending) {
+            *reinterpret_cast<U4*>(ring + ((filled + 16 * j) & (RCX_R8_RING_BYTES - 1))) = pend;
+            filled += 128;
+            pending = false;
+        }
+        if (on && p + 128 >= filled) { // the older half is behind p: ask for what follows (>= 7 steps before it can be needed)
+            pend = load16(filled);
+            pending = true;
+        }
+        u32 sym = 0;
         if (on) { // cppans.h:636-639 (simdDecSym :412-440)
             const u32 slot_ = x & 4095u;
-            const u32 sym = slot2sym[slot_];
-            const u32 lo = cum16[sym], hi = cum16[sym + 1];
-            out[8 * g + j] = (u8)sym;
-            x = (hi - lo) * (x >> 12) + (slot_ - lo);
+            const u32 f = first[slot_ >> 2];
+            const u32 e0 = table[f], e1 = table[f + 1], e2 = table[f + 2], e3 = table[f + 3];
+            u32 e = e0;
+            if ((e1 & 4095u) <= slot_) e = e1;
+            if ((e2 & 4095u) <= slot_) e = e2;
+            if ((e3 & 4095u) <= slot_) e = e3;
+            sym = e >> 24;
+            x = (((e >> 12) & 4095u) + 1u) * (x >> 12) + slot_ - (e & 4095u); // freq * (x >> 12) + bias
         }
+        if (on) obuf[8 * (g & 7u) + j] = (u8)sym;
         // cppans.h:640-641 (simdDecRenorm :443-488): the states below 2^16 take one word each, in state order
         const bool need = on && x < (1u << 16);
         const u32 mask = rcx_octet_ballot(need, lane);
-        const u32 before = (u32)__popc(mask & ((1u << j) - 1u));
-        const u32 word = (u32)__shfl((int)cand, (int)((lane & ~7u) + before), 64);
+        const u32 o = (p + 2 * (u32)__popc(mask & ((1u << j) - 1u))) & (RCX_R8_RING_BYTES - 1);
+        u32 word;
+        if (even) word = *reinterpret_cast<const unsigned short*>(ring + o);
+        else word = (u32)ring[o] | ((u32)ring[(o + 1) & (RCX_R8_RING_BYTES - 1)] << 8);
         if (need) x = (x << 16) | word;
-        wp += 2 * (u32)__popc(mask);
-        if (on && wp > stream_len) ran_dry = true;
+        p += 2 * (u32)__popc(mask);
+        if ((g & 7u) == 7u) { // eight steps = 64 symbols of the block: 8 bytes per lane
+            rcx_octet_sync();
+            if (on) {
+                if (out8) *reinterpret_cast<u64*>(out + 8 * (g - 7) + 8 * j) = *reinterpret_cast<const u64*>(obuf + 8 * j);
+                else
+                    for (u32 k = 0; k < 8; ++k) out[8 * (g - 7) + 8 * j + k] = obuf[8 * j + k];
+            }
+            rcx_octet_sync();
+        }
     }
-    // cppans.h:643-647: the last n mod 8 symbols step without renormalising
-    if (live && 8 * groups + j < len) {
-        const u32 slot_ = x & 4095u;
-        out[8 * groups + j] = slot2sym[slot_];
+    // the steps since the last full group of eight
+    if (live) {
+        const u32 done = groups & ~7u;
+        for (u32 g = done; g < groups; ++g) out[8 * g + j] = obuf[8 * (g & 7u) + j];
+        // cppans.h:643-647: the last n mod 8 symbols step without renormalising
+        if (8 * groups + j < len) {
+            const u32 slot_ = x & 4095u;
+            const u32 f = first[slot_ >> 2];
+            u32 e = table[f];
+            if ((table[f + 1] & 4095u) <= slot_) e = table[f + 1];
+            if ((table[f + 2] & 4095u) <= slot_) e = table[f + 2];
+            if ((table[f + 3] & 4095u) <= slot_) e = table[f + 3];
+            out[8 * groups + j] = (u8)(e >> 24);
+        }
+        // a valid stream holds every word that was taken (cppans.h:479-481 reads on regardless)
+        if (j == 0 && (u64)(words - s) + (p - (u32)(words - origin)) > stream_len) rcx_flag(status, RCX_ST_CORRUPT, blk);
     }
-    if (live && j == 0 && ran_dry) rcx_flag(status, RCX_ST_CORRUPT, blk);
 }
 
 // The one-state format (cppans.h:532-564): all lanes of the octet carry the state; the symbol of a slot is found by

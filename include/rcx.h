@@ -77,7 +77,7 @@ enum {
  * MAX_SIZE (cpprcoder.h:329): past RCX_MAX_BLOCK symbols the lane keeps its own total and halves the table. */
 #define RCX_MAX_BLOCK ((1u << 24) - 256u)
 #define RCX_MAX_STREAM 0x7FFFFFFFu
-#define RCX_MAX_RANS_STREAM 0x7FFFFB00u /* rANS single streams: 2n + 1096 must fit the u32 sizes of cppans.h:72-76 */
+#define RCX_MAX_RANS_STREAM 0x7FFF0000u /* rANS single streams: 2n + 1096 must fit the u32 sizes of cppans.h:72-76 */
 
 typedef struct rcx_ctx rcx_ctx;
 

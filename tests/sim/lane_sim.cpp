@@ -62,7 +62,7 @@ int sim_encode_blocks(const uint8_t* src, uint64_t n, uint32_t block, uint8_t* s
     for (uint64_t b = 0; b < nblocks; ++b) {
         uint64_t at = b * block;
         uint32_t len = (uint32_t)((n - at) < block ? (n - at) : block);
-        Tree tree{lds.data() + lane};
+        Tree tree{reinterpret_cast<u32*>(lds.data()) + (RCX_TREE_PLANAR ? 1 : 4) * lane};
         tree.reset();
         EncLane e;
         e.begin(slots, (u32)(b * slot), (u32)slot, len);
@@ -79,7 +79,7 @@ int sim_encode_blocks(const uint8_t* src, uint64_t n, uint32_t block, uint8_t* s
 void sim_stream_encode_track(const uint8_t* src, uint32_t n, uint64_t sink16, uint8_t* slot, uint64_t slot_bytes, uint32_t* out)
 {
     std::vector<U4> lds((RCX_GROUPS + 1) * RCX_LANES);
-    Tree tree{lds.data() + 3};
+    Tree tree{reinterpret_cast<u32*>(lds.data()) + (RCX_TREE_PLANAR ? 1 : 4) * 3};
     tree.reset();
     EncLane e;
     e.begin(slot, 0, (u32)slot_bytes, n);
@@ -94,7 +94,7 @@ void sim_stream_encode_track(const uint8_t* src, uint32_t n, uint64_t sink16, ui
 uint32_t sim_stream_decode_track(const uint8_t* comp, uint64_t comp_size, uint32_t count, uint8_t* dst)
 {
     std::vector<U4> lds((RCX_GROUPS + 1) * RCX_LANES);
-    Tree tree{lds.data() + 9};
+    Tree tree{reinterpret_cast<u32*>(lds.data()) + (RCX_TREE_PLANAR ? 1 : 4) * 9};
     tree.reset();
     std::vector<uint8_t> pad(comp_size + 64);
     uint8_t* base = pad.data();
@@ -116,7 +116,7 @@ uint32_t sim_stream_decode_track(const uint8_t* comp, uint64_t comp_size, uint32
 uint32_t sim_stream_encode_long(const uint8_t* src, uint32_t n, uint8_t* slot, uint64_t slot_bytes)
 {
     std::vector<U4> lds((RCX_GROUPS + 1) * RCX_LANES);
-    Tree tree{lds.data() + 11};
+    Tree tree{reinterpret_cast<u32*>(lds.data()) + (RCX_TREE_PLANAR ? 1 : 4) * 11};
     tree.reset();
     EncLane e;
     e.begin(slot, 0, (u32)slot_bytes, n);
@@ -129,7 +129,7 @@ uint32_t sim_stream_encode_long(const uint8_t* src, uint32_t n, uint8_t* slot, u
 uint32_t sim_stream_decode_long(const uint8_t* comp, uint64_t comp_size, uint32_t count, uint8_t* dst)
 {
     std::vector<U4> lds((RCX_GROUPS + 1) * RCX_LANES);
-    Tree tree{lds.data() + 12};
+    Tree tree{reinterpret_cast<u32*>(lds.data()) + (RCX_TREE_PLANAR ? 1 : 4) * 12};
     tree.reset();
     std::vector<uint8_t> pad(comp_size + 64);
     uint8_t* base = pad.data();
@@ -162,7 +162,7 @@ uint64_t sim_decode_blocks(const uint8_t* comp, const uint64_t* offsets, uint64_
         uint32_t len = (uint32_t)((n - at) < block ? (n - at) : block);
         uint64_t s0 = offsets[b], s1 = offsets[b + 1];
         if (s1 < s0 || s1 - s0 < 9) return b + 1;
-        Tree tree{lds.data() + lane};
+        Tree tree{reinterpret_cast<u32*>(lds.data()) + (RCX_TREE_PLANAR ? 1 : 4) * lane};
         tree.reset();
         DecLane d;
         // the device code loads aligned 16-byte pieces that may start before / end after the stream:
