@@ -819,6 +819,101 @@ int rcx_stream_decode(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
     return result;
 }
 
+// ---------------------------------------------------------------------------
+// The resumable single-stream decoder: AdaptiveRangeDecoder<T>::decode fed piece by piece (cpprcoder.h:872-924).
+// ---------------------------------------------------------------------------
+struct rcx_dstream {
+    rcx_ctx* ctx = nullptr;
+    RcxDState* state = nullptr; // device
+    u8* in = nullptr;           // device: every byte accepted so far
+    u64 in_bytes = 0, in_cap = 0;
+    u8* out = nullptr;          // device: one launch's symbols
+    u32* result = nullptr;      // device: {made, finished, declared, produced}
+    u32* result_host = nullptr; // pinned
+    bool finished = false;
+    u32 declared = 0, produced = 0;
+};
+#define RCX_DSTREAM_CHUNK (1u << 20) /* symbols per launch */
+
+int rcx_dstream_create(rcx_ctx* c, rcx_dstream** out)
+{
+    if (!c || !out) return RCX_E_ARG;
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(c->device));
+    rcx_dstream* d = new (std::nothrow) rcx_dstream();
+    if (!d) return RCX_E_NOMEM;
+    d->ctx = c;
+    if (hipMalloc(reinterpret_cast<void**>(&d->state), sizeof(RcxDState)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d->out), RCX_DSTREAM_CHUNK) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d->result), 4 * sizeof(u32)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&d->result_host), 4 * sizeof(u32), hipHostMallocDefault) != hipSuccess ||
+        hipMemset(d->state, 0, sizeof(RcxDState)) != hipSuccess) {
+        rcx_dstream_destroy(d);
+        return RCX_E_NOMEM;
+    }
+    *out = d;
+    return RCX_OK;
+}
+
+void rcx_dstream_destroy(rcx_dstream* d)
+{
+    if (!d) return;
+    if (d->ctx) (void)hipSetDevice(d->ctx->device);
+    if (d->state) (void)hipFree(d->state);
+    if (d->in) (void)hipFree(d->in);
+    if (d->out) (void)hipFree(d->out);
+    if (d->result) (void)hipFree(d->result);
+    if (d->result_host) (void)hipHostFree(d->result_host);
+    delete d;
+}
+
+int rcx_dstream_decode(rcx_dstream* d, const uint8_t* bytes, uint64_t size, uint8_t* dst, uint64_t dst_cap,
+                       uint64_t* produced_now, uint32_t* request_size)
+{
+    if (!d || !produced_now || (size && !bytes) || (dst_cap && !dst)) return RCX_E_ARG;
+    *produced_now = 0;
+    if (request_size) *request_size = 0;
+    if (d->finished) return RCX_OK;
+    HIP_TRY(hipSetDevice(d->ctx->device));
+    if (d->in_bytes == 0 && size < 8) { // cpprcoder.h:877-880: State_Init wants its 8 bytes in one call and keeps nothing
+        if (request_size) *request_size = 8;
+        return RCX_PENDING;
+    }
+    if (size) { // append
+        if (d->in_bytes + size > d->in_cap) {
+            u64 cap = d->in_cap ? d->in_cap : (1u << 16);
+            while (cap < d->in_bytes + size) cap *= 2;
+            u8* bigger = nullptr;
+            if (hipMalloc(reinterpret_cast<void**>(&bigger), cap) != hipSuccess) return RCX_E_NOMEM;
+            if (d->in_bytes) HIP_TRY(hipMemcpy(bigger, d->in, d->in_bytes, hipMemcpyDeviceToDevice));
+            if (d->in) (void)hipFree(d->in);
+            d->in = bigger;
+            d->in_cap = cap;
+        }
+        HIP_TRY(hipMemcpy(d->in + d->in_bytes, bytes, size, hipMemcpyHostToDevice));
+        d->in_bytes += size;
+    }
+    u64 made_total = 0;
+    for (;;) {
+        const u64 room64 = dst_cap - made_total;
+        const u32 room = room64 > RCX_DSTREAM_CHUNK ? RCX_DSTREAM_CHUNK : (u32)room64;
+        hipLaunchKernelGGL(rcx_dec_resume_k, dim3(1), dim3(64), 0, nullptr, d->state, d->in, d->in_bytes, d->out, room, d->result);
+        if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
+        HIP_TRY(hipMemcpy(d->result_host, d->result, 4 * sizeof(u32), hipMemcpyDeviceToHost));
+        const u32 made = d->result_host[0];
+        d->finished = d->result_host[1] != 0;
+        d->declared = d->result_host[2];
+        d->produced = d->result_host[3];
+        if (made) HIP_TRY(hipMemcpy(dst + made_total, d->out, made, hipMemcpyDeviceToHost));
+        made_total += made;
+        if (d->finished || made < room || made_total == dst_cap) break; // done, input dry, or dst full
+    }
+    *produced_now = made_total;
+    if (d->finished) return RCX_OK;
+    if (request_size) *request_size = d->declared - d->produced; // cpprcoder.h:901-903 / :909-911
+    return RCX_PENDING;
+}
+
 #if defined(RCX_STAMP_DEC)
 int rcx_debug_dec_stamps(unsigned long long* out8)
 {

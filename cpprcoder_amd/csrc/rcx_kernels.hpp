@@ -335,6 +335,60 @@ __global__ __launch_bounds__(64) void rcx_dec_adaptive_k(const u8* __restrict__ 
     }
 }
 
+// ===========================================================================
+// The resumable single-stream decoder (rcx_dstream_*, include/rcx.h): AdaptiveRangeDecoder<T>::decode called
+// piece by piece (cpprcoder.h:872-924).  One lane; its whole state -- low, range, the model, how far it got --
+// lives in `st` between launches, so every call decodes only what the new bytes allow (the reference does the
+// same on its object).  A symbol is started only if the bytes its renormalisation needs have arrived (the
+// reference stops in the middle of the renormalisation, :901-903, and resumes there: same bytes, same symbols).
+// ===========================================================================
+struct alignas(16) RcxDState {
+    U4 tree[RCX_GROUPS];
+    u32 low, range, total, started;
+    u32 declared, produced; // produced counts towards max(declared, 1) (cpprcoder.h:912)
+    u64 consumed;
+};
+
+__global__ __launch_bounds__(64) void rcx_dec_resume_k(RcxDState* __restrict__ st, const u8* __restrict__ in, u64 avail, u8* __restrict__ out,
+                                                       u32 room, u32* __restrict__ result)
+{
+    __shared__ U4 lds[RCX_GROUPS * RCX_LANES];
+    if (threadIdx.x != 0) return;
+    Tree tree{reinterpret_cast<u32*>(lds)};
+    u32 low = st->low, range = st->range, total = st->total, produced = st->produced, declared = st->declared;
+    u64 consumed = st->consumed;
+    if (!st->started) { // cpprcoder.h:859-870, :877-896: the caller made sure the first 8 bytes are here
+        declared = (u32)in[0] | ((u32)in[1] << 8) | ((u32)in[2] << 16) | ((u32)in[3] << 24);
+        low = ((u32)in[4] << 24) | ((u32)in[5] << 16) | ((u32)in[6] << 8) | (u32)in[7];
+        range = 0x00FFFFFFu;
+        total = 256;
+        consumed = 8;
+        produced = 0;
+        tree.reset();
+    } else {
+        for (u32 g = 0; g < RCX_GROUPS; ++g) tree.store(g, st->tree[g]);
+    }
+    const u32 want = declared ? declared : 1u; // :912: the size test comes after the first writeByte
+    u32 made = 0;
+    while (produced < want && made < room) {
+        const u32 k8 = rcx_clz(range) & 0x18u; // :926-940
+        const u32 need = k8 >> 3;
+        if (consumed + need > avail) break;     // input ran dry before this symbol (:901-903)
+        for (u32 b = 0; b < need; ++b) low = (low << 8) | in[consumed + b];
+        consumed += need;
+        range <<= k8;
+        out[made++] = (u8)rcx_decode_plain(tree, low, range, total);
+        produced += 1;
+    }
+    st->low = low, st->range = range, st->total = total, st->started = 1;
+    st->declared = declared, st->produced = produced, st->consumed = consumed;
+    for (u32 g = 0; g < RCX_GROUPS; ++g) st->tree[g] = tree.group(g);
+    result[0] = made;
+    result[1] = produced >= want ? 1u : 0u; // finished
+    result[2] = declared;
+    result[3] = produced;
+}
+
 #include "rcx_oct.hpp"
 #include "variants/rcx_variants.hpp"
 #include "rcx_static.hpp"

@@ -694,3 +694,48 @@ struct DecLane {
         return c;
     }
 };
+
+// ---------------------------------------------------------------------------
+// One decoder step on plain state, for the resumable single-stream decoder (rcx_dstream_*): no input ring, the
+// caller has already shifted the bytes in (cpprcoder.h:926-940).  t = range / total as a true division, find() in
+// the scaled domain as DecLane::step, update with the halving (cpprcoder.h:900-917, :1134-1177).
+// ---------------------------------------------------------------------------
+template <class TreeT>
+RCX_DEV u32 rcx_decode_plain(const TreeT& tree, u32& low, u32& range, u32& total)
+{
+    const u32 t = range / total;           // :904
+    const u32 top = rcx_mul24(total, t);
+    u32 rem = low, c = 0;
+    u32 path_g[4], path_p[4], path_hit[4];
+    u32 g = RCX_G_L3;
+    for (u32 level = 0; level < 4; ++level) {
+        const U4 v = tree.group(g);
+        const u32 s2 = v.x + v.y, s3 = s2 + v.z;
+        const u32 a = rcx_mul24(v.x, t), b = rcx_mul24(s2, t), d = rcx_mul24(s3, t);
+        u32 base = 0, p = 0, hit = v.x;
+        if (rem >= a) { base = a; p = 1; hit = v.y; }
+        if (rem >= b) { base = b; p = 2; hit = v.z; }
+        if (rem >= d) { base = d; p = 3; hit = v.w; }
+        rem -= base;
+        path_g[level] = g;
+        path_p[level] = p;
+        path_hit[level] = hit;
+        c = (c << 2) | p;
+        g = (level == 0 ? RCX_G_L2 : level == 1 ? RCX_G_L1 : RCX_G_L0) + c;
+    }
+    u32 f = path_hit[3];
+    if (low >= top) { // a target at or past the total: find() falls through with code 0, count = total (:1220-1242)
+        c = 0;
+        rem = low - top;
+        f = tree.group(RCX_G_L0).x;
+        tree.update(0);
+    } else {
+        for (u32 level = 0; level < 4; ++level) tree.put(path_g[level], path_p[level], path_hit[level] + 1);
+    }
+    low = rem;               // :906
+    range = rcx_mul24(f, t); // :907
+    total += 1;              // :1138
+    if (total >= RCX_HALVE_AT) total = tree.halve();
+    return c;
+}
+

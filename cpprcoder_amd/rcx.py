@@ -27,6 +27,7 @@ EXPORTS = (
     "rcx_encode_blocks", "rcx_decode_blocks", "rcx_stream_encode", "rcx_stream_decode", "rcx_ctx_set_timing",
     "rcx_ctx_get_timing", "rcx_ctx_last_redo",
     "rcx_block_bound_for", "rcx_encode_bound_for", "rcx_ctx_reserve_for",
+    "rcx_dstream_create", "rcx_dstream_destroy", "rcx_dstream_decode",
     "rcx_comm_unique_id", "rcx_comm_create", "rcx_comm_destroy", "rcx_comm_rank", "rcx_comm_size", "rcx_exchange_plan",
     "rcx_allgatherv_segments",
 )
@@ -76,6 +77,10 @@ def lib() -> C.CDLL:
         L.rcx_ctx_set_timing.restype, L.rcx_ctx_set_timing.argtypes = i32, [vp, i32]
         L.rcx_ctx_get_timing.restype, L.rcx_ctx_get_timing.argtypes = i32, [vp, C.POINTER(C.c_double), C.POINTER(u64), i32]
         L.rcx_ctx_last_redo.restype, L.rcx_ctx_last_redo.argtypes = i32, [vp, u64, C.POINTER(u64)]
+        L.rcx_dstream_create.restype, L.rcx_dstream_create.argtypes = i32, [vp, C.POINTER(vp)]
+        L.rcx_dstream_destroy.restype, L.rcx_dstream_destroy.argtypes = None, [vp]
+        L.rcx_dstream_decode.restype = i32
+        L.rcx_dstream_decode.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64), C.POINTER(u32)]
         L.rcx_comm_unique_id.restype, L.rcx_comm_unique_id.argtypes = i32, [vp]
         L.rcx_comm_create.restype, L.rcx_comm_create.argtypes = i32, [i32, vp, i32, i32, C.POINTER(vp)]
         L.rcx_comm_destroy.restype, L.rcx_comm_destroy.argtypes = None, [vp]
@@ -216,6 +221,10 @@ class Context:
         st = lib().rcx_stream_decode(self._h, coder, src.ctypes.data, len(src), dst.ctypes.data, sink_capacity, C.byref(size), C.byref(req))
         return st, req.value, bytes(dst[: size.value])
 
+    # ---- the resumable decoder ----------------------------------------------
+    def dstream(self) -> "DStream":
+        return DStream(self)
+
     # ---- per-kernel device time -------------------------------------------
     def set_timing(self, enabled: bool) -> None:
         _check(lib().rcx_ctx_set_timing(self._h, int(enabled)), "rcx_ctx_set_timing")
@@ -232,3 +241,30 @@ class Context:
         _check(lib().rcx_ctx_get_timing(self._h, ms, launches, int(reset)), "rcx_ctx_get_timing")
         names = ("encode", "scan", "scatter", "decode")
         return {names[i]: {"ms": ms[i], "launches": int(launches[i])} for i in range(T_COUNT)}
+
+
+class DStream:
+    """One rcx_dstream: AdaptiveRangeDecoder<T>::decode fed piece by piece (cpprcoder.h:872-924)."""
+
+    def __init__(self, ctx: Context):
+        self._h = C.c_void_p()
+        _check(lib().rcx_dstream_create(ctx._h, C.byref(self._h)), "rcx_dstream_create")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().rcx_dstream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def decode(self, piece, room: int):
+        """-> (status, request_size, symbols decoded now)"""
+        src = _np_u8(piece)
+        dst = np.zeros(max(room, 1) + 16, dtype=np.uint8)
+        got, req = C.c_uint64(), C.c_uint32()
+        st = lib().rcx_dstream_decode(self._h, src.ctypes.data if len(src) else None, len(src), dst.ctypes.data, room, C.byref(got), C.byref(req))
+        return st, req.value, bytes(dst[: got.value])

@@ -17,8 +17,9 @@
  *     size has been seen (returning {Status_Pending, remaining} like the reference)
  *     and only then emits bytes into the sink; the sink's final contents, the return
  *     values, and the behaviour of a sink that fills up are the reference's.
- *   - decode() re-runs over everything it has been fed so far when it is called again
- *     after Status_Pending.
+ *   - decode() keeps its coder state on the GPU between calls (rcx_dstream), so a stream fed in pieces costs what
+ *     the pieces cost; after a sink that filled up it keeps answering Status_Pending (the reference's decoder has
+ *     lost a symbol at that point, cpprcoder.h:909-911, and is unusable as well).
  *   - One stream is one GPU lane: this facade is for drop-in compatibility.  Throughput
  *     comes from coding many blocks at once through rcx_encode_blocks_device (rcx.h),
  *     see BlockCoder below.
@@ -263,43 +264,59 @@ private:
     std::vector<u8> input_;
 };
 
-//--- AdaptiveRangeDecoder (cpprcoder.h:809-940)
+//--- AdaptiveRangeDecoder (cpprcoder.h:809-940): the decoder's state lives on the GPU between calls (rcx_dstream)
 template<class T = MemoryStream>
 class AdaptiveRangeDecoder
 {
 public:
-    AdaptiveRangeDecoder() : stream_(nullptr), outSize_(0), done_(false) {}
+    AdaptiveRangeDecoder() : stream_(nullptr), decoder_(nullptr), outSize_(0), declared_(0), started_(false), dead_(false) {}
+    ~AdaptiveRangeDecoder() { rcx_dstream_destroy(decoder_); }
 
     bool initialize(T& stream) // cpprcoder.h:859-870
     {
         stream_ = &stream;
         outSize_ = 0;
-        done_ = false;
-        fed_.clear();
+        declared_ = 0;
+        started_ = false;
+        dead_ = false;
+        rcx_dstream_destroy(decoder_);
+        decoder_ = nullptr;
         return true;
     }
 
-    // cpprcoder.h:872-924
+    // cpprcoder.h:872-924: every call decodes what its bytes allow and writes it to the sink
     Result decode(s32 size, const u8* bytes)
     {
-        if (fed_.empty() && size < 8) return {Status_Pending, 8}; // State_Init needs 8 bytes in one call
-        fed_.insert(fed_.end(), bytes, bytes + size);
+        if (dead_) return {Status_Pending, declared_ - outSize_}; // the reference's decoder is unusable after a full sink too
+        if (!started_ && size < 8) return {Status_Pending, 8};    // State_Init needs 8 bytes in one call (:877-880)
         rcx_ctx* ctx = facade_context();
         if (!ctx) return {Status_Error, 0};
-        const u32 declared = static_cast<u32>(fed_[0]) | (static_cast<u32>(fed_[1]) << 8) | (static_cast<u32>(fed_[2]) << 16) |
-                             (static_cast<u32>(fed_[3]) << 24);
-        const uint64_t want = declared ? declared : 1;
-        std::vector<u8> out(static_cast<size_t>(want) + 64);
-        uint64_t produced = 0;
-        uint32_t req = 0;
-        int st = rcx_stream_decode(ctx, RCX_CODER_ADAPTIVE, fed_.data(), fed_.size(), out.data(), want, &produced, &req);
-        if (st != RCX_OK && st != RCX_PENDING) return {Status_Error, 0};
-        for (uint64_t i = outSize_; i < produced; ++i) {
-            if (!stream_->writeByte(out[i])) return {Status_Pending, declared - outSize_}; // cpprcoder.h:909-911
-            ++outSize_;
+        if (!decoder_ && rcx_dstream_create(ctx, &decoder_) != RCX_OK) return {Status_Error, 0};
+        if (!started_) {
+            declared_ = static_cast<u32>(bytes[0]) | (static_cast<u32>(bytes[1]) << 8) | (static_cast<u32>(bytes[2]) << 16) |
+                        (static_cast<u32>(bytes[3]) << 24);
+            started_ = true;
         }
-        if (st == RCX_PENDING) return {Status_Pending, declared - outSize_}; // input ran dry (cpprcoder.h:901-903)
-        return {Status_Success, 0};
+        if (chunk_.empty()) chunk_.resize(1u << 16);
+        const u8* feed = bytes;
+        uint64_t feed_size = static_cast<uint64_t>(size);
+        for (;;) {
+            uint64_t got = 0;
+            uint32_t req = 0;
+            const int st = rcx_dstream_decode(decoder_, feed, feed_size, chunk_.data(), chunk_.size(), &got, &req);
+            feed = nullptr;
+            feed_size = 0;
+            if (st != RCX_OK && st != RCX_PENDING) return {Status_Error, 0};
+            for (uint64_t i = 0; i < got; ++i) {
+                if (!stream_->writeByte(chunk_[i])) { // cpprcoder.h:909-911
+                    dead_ = true;
+                    return {Status_Pending, declared_ - outSize_};
+                }
+                ++outSize_;
+            }
+            if (st == RCX_OK) return {Status_Success, 0};
+            if (got < chunk_.size()) return {Status_Pending, req}; // the input ran dry (cpprcoder.h:901-903)
+        }
     }
 
 private:
@@ -307,9 +324,12 @@ private:
     AdaptiveRangeDecoder& operator=(const AdaptiveRangeDecoder&) = delete;
 
     T* stream_;
+    rcx_dstream* decoder_;
     u32 outSize_;
-    bool done_;
-    std::vector<u8> fed_;
+    u32 declared_;
+    bool started_;
+    bool dead_;
+    std::vector<u8> chunk_;
 };
 
 //--- RangeEncoder: the static two-pass coder (cpprcoder.h:321-619); encode and decode are members of one class
@@ -354,7 +374,13 @@ public:
         const u32 declared = static_cast<u32>(bytes[0]) | (static_cast<u32>(bytes[1]) << 8) | (static_cast<u32>(bytes[2]) << 16) |
                              (static_cast<u32>(bytes[3]) << 24);
         if (declared == 0) return true;
-        std::vector<u8> out(static_cast<size_t>(declared) + 64);
+        if (declared > MAX_SIZE) return false; // a damaged header: nothing the encoder could have written (cpprcoder.h:329)
+        std::vector<u8> out;
+        try {
+            out.resize(static_cast<size_t>(declared) + 64);
+        } catch (...) {
+            return false; // no memory for what the header claims
+        }
         uint64_t produced = 0;
         int st = rcx_stream_decode(ctx, RCX_CODER_STATIC, bytes, size, out.data(), declared, &produced, nullptr);
         if (st != RCX_OK && st != RCX_ERROR) return false;

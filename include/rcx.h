@@ -165,6 +165,23 @@ int rcx_stream_decode(rcx_ctx* ctx, int coder, const uint8_t* comp, uint64_t com
                       uint8_t* dst, uint64_t sink_capacity, uint64_t* dst_size, uint32_t* request_size);
 
 /*
+ * The adaptive decoder as a resumable object: AdaptiveRangeDecoder<T>::initialize + decode(size, bytes) called piece by
+ * piece (cpprcoder.h:859-924).  The decoder's state (low, range, the frequency table, how far it got) stays on the GPU
+ * between calls, so every call costs what its new bytes allow, as with the reference's object.
+ *   rcx_dstream_decode   feed `size` more bytes of the stream; the symbols that can be decoded now, at most dst_cap of
+ *       them (the room the caller's sink has), go to dst and *produced_now says how many.  RCX_OK once max(declared, 1)
+ *       symbols have been produced (cpprcoder.h:912), else RCX_PENDING with *request_size = declared - produced so
+ *       far: the input ran dry (cpprcoder.h:901-903) or dst is full (call again with size 0 to go on -- unlike the
+ *       reference, whose sink-full return has already swallowed a symbol, cpprcoder.h:909-911).  A first call with
+ *       fewer than 8 bytes keeps nothing and asks for 8 (cpprcoder.h:877-880).
+ */
+typedef struct rcx_dstream rcx_dstream;
+int rcx_dstream_create(rcx_ctx* ctx, rcx_dstream** out);
+void rcx_dstream_destroy(rcx_dstream* stream);
+int rcx_dstream_decode(rcx_dstream* stream, const uint8_t* bytes, uint64_t size, uint8_t* dst, uint64_t dst_cap,
+                       uint64_t* produced_now, uint32_t* request_size);
+
+/*
  * Multi-GPU (new; the reference has no multi-device code).  Blocks are independent, so n bytes are sharded over the
  * GPUs of a node as contiguous block ranges and coded with the calls above, no collective involved.  The one real
  * exchange of the path is putting the compressed segments of all GPUs -- and their block tables -- together on

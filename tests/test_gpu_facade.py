@@ -113,7 +113,11 @@ def test_facade_rans(exe, tmp_path, oracle):
                 continue  # the reference's own calc_encoded_size is too small for encode_simd below 16 symbols
             ref = oracle.rans_encode(v, bool(simd))
             (size, cap), out = run(exe, tmp_path, "renc", v, 0, simd)
-            assert size == len(ref) and cap == 2 * n + 1032 and out == ref, (n, simd)
+            assert cap == 2 * n + 1032
+            if len(ref) > cap:  # one repeated byte through encode_simd: 2n + 1064 bytes, more than calc_encoded_size allows
+                assert size == 0  # cppans.h:599-601 (the reference has written in front of its destination by then)
+                continue
+            assert size == len(ref) and out == ref, (n, simd)
             (ret, _), back = run(exe, tmp_path, "rdec", ref, n, simd)
             assert back == v and ret == (n if simd else len(ref) - 1032), (n, simd)
             (ret, _), _ = run(exe, tmp_path, "rdec", ref, n - 1, simd)  # destination too small: 0 (cppans.h:541, :618)

@@ -635,3 +635,58 @@ def test_static_histogram_past_65535_symbols(ctx, oracle):
         assert_same_blocks(payload, offsets, slots, sizes)
         back, st, _ = gpu_decode(ctx, payload, offsets, len(data), block, coder=1)
         assert st == 0 and np.array_equal(back, data)
+
+
+def test_resumable_decoder_fed_in_pieces(ctx, oracle, golden):
+    """rcx_dstream_*: AdaptiveRangeDecoder<T>::decode called piece by piece (cpprcoder.h:872-924).  The coder state stays
+    on the GPU between calls; whatever the split, the symbols are the reference's, {Pending, remaining} is reported
+    while the input is short (cpprcoder.h:901-903), and a stream fed in many pieces costs what its pieces cost."""
+    import time
+    from cpprcoder_amd import rcx
+    files = workloads.canterbury_files()
+    cases = [b"", b"hello world", workloads.zipf(20000, 5).tobytes(), workloads.uniform(70000, 3).tobytes(), files["fields.c"]]
+    for v in cases:
+        comp = oracle.adaptive_encode(v)[1]
+        want = v if v else b"\x00"  # cpprcoder.h:912: a stream declaring 0 bytes yields one
+        for piece in (8, 9, 100, 4096, len(comp)):
+            d = ctx.dstream()
+            out, at, st, rq = b"", 0, rcx.PENDING, 0
+            while at < len(comp) and st == rcx.PENDING:
+                st, rq, got = d.decode(comp[at: at + piece], 1 << 20)
+                at += piece
+                out += got
+                assert want.startswith(out)
+                if st == rcx.PENDING:
+                    assert rq == len(v) - len(out)
+            assert st == rcx.OK and out == want, (len(v), piece)
+            d.close()
+    # fewer than 8 bytes first: nothing is kept, 8 are asked for (cpprcoder.h:877-880)
+    d = ctx.dstream()
+    comp = oracle.adaptive_encode(cases[2])[1]
+    assert d.decode(comp[:5], 100)[:2] == (rcx.PENDING, 8)
+    st, rq, got = d.decode(comp, 100)  # a sink with room for 100: the caller comes back for more with no new bytes
+    assert (st, rq, got) == (rcx.PENDING, len(cases[2]) - 100, cases[2][:100])
+    rest = b""
+    while st == rcx.PENDING:
+        st, rq, got = d.decode(b"", 3000)
+        rest += got
+    assert st == rcx.OK and cases[2][:100] + rest == cases[2]
+    d.close()
+    # damaged input decodes like the reference (find()'s fall-through included)
+    for key in ("decode_junk_64", "decode_allff_64"):
+        pin = golden["kat"]["pins"][key]
+        d = ctx.dstream()
+        st, rq, got = d.decode(bytes.fromhex(pin["input_hex"]), 64)
+        assert [st, rq] == pin["status"] and got.hex() == pin["out_hex"]
+        d.close()
+    # 2 MiB in 4 KiB pieces: 500+ calls, each decoding only its own symbols
+    big = workloads.zipf(2 << 20, 77).tobytes()
+    comp = oracle.adaptive_encode(big)[1]
+    d = ctx.dstream()
+    t0, out = time.time(), []
+    for at in range(0, len(comp), 4096):
+        st, rq, got = d.decode(comp[at: at + 4096], 1 << 20)
+        out.append(got)
+    assert st == rcx.OK and b"".join(out) == big
+    assert time.time() - t0 < 60
+    d.close()
