@@ -39,6 +39,7 @@ struct rcx_ctx {
     int enc_lanes = 0;       // blocks per multi-wave encode workgroup: 0 = from the block count, else 1..64 (RCX_ENC_LANES)
     int dec_quads = 0;       // blocks per quad-decoder wave: 0 = from the block count, else 1, 2, 4, 8, 16 (RCX_DEC_QUADS)
     int cus = 256;           // compute units of the device
+    bool rans1_lds_set = false; // rcx_enc_rans1_k has been allowed its 128 KiB of dynamic LDS
     bool rans_track = false; // the single-stream rANS decode wants the payload bytes consumed (status[2])
     // scratch
     u8* slots = nullptr;
@@ -47,6 +48,8 @@ struct rcx_ctx {
     u64 sizes_count = 0;
     u32* starts = nullptr;      // rANS: where each block's stream begins in its slot (the encoders write backwards)
     u64 starts_count = 0;
+    u32* models = nullptr;      // one-state rANS: every block's scaled cumulative counts + coding table (rcx_rans_model_k)
+    u64 models_bytes = 0;
     u32* redo = nullptr;        // decode: blocks the quad kernel leaves to the one-lane kernel (corrupt input only)
     u64 redo_count = 0;
     DivEntry* divtab = nullptr;
@@ -204,6 +207,10 @@ int reserve(rcx_ctx* c, u64 n, u32 block, int coder = RCX_CODER_ADAPTIVE)
         r = grow(reinterpret_cast<void**>(&c->starts), &bytes, (nblocks + 1) * sizeof(u32));
         if (r != RCX_OK) return r;
         c->starts_count = bytes / sizeof(u32);
+        if (coder == RCX_CODER_RANS) {
+            r = grow(reinterpret_cast<void**>(&c->models), &c->models_bytes, nblocks * RCX_RANS_MODEL_DW * sizeof(u32));
+            if (r != RCX_OK) return r;
+        }
     }
     return ensure_redo(c, nblocks);
 }
@@ -300,6 +307,7 @@ void rcx_ctx_destroy(rcx_ctx* c)
     if (c->slots) (void)hipFree(c->slots);
     if (c->sizes) (void)hipFree(c->sizes);
     if (c->starts) (void)hipFree(c->starts);
+    if (c->models) (void)hipFree(c->models);
     if (c->redo) (void)hipFree(c->redo);
     if (c->divtab) (void)hipFree(c->divtab);
     if (c->status) (void)hipFree(c->status);
@@ -368,9 +376,26 @@ int rcx_encode_blocks_device(rcx_ctx* c, int coder, const void* d_src, uint64_t 
             if (coder == RCX_CODER_RANS8)
                 hipLaunchKernelGGL(rcx_enc_rans_k<true>, dim3(grid), dim3(256), 0, s, static_cast<const u8*>(d_src), n, block, nblocks, c->slots,
                                    slot, c->sizes, c->starts, c->status);
-            else
-                hipLaunchKernelGGL(rcx_enc_rans_k<false>, dim3(grid), dim3(256), 0, s, static_cast<const u8*>(d_src), n, block, nblocks, c->slots,
-                                   slot, c->sizes, c->starts, c->status);
+            else {
+                // one state per block = one chain per block: the model by octets, then the coding loop one lane per
+                // block, `lanes` blocks per wave so that every SIMD has a wave before any wave carries 64
+                hipLaunchKernelGGL(rcx_rans_model_k<14>, dim3(grid), dim3(256), 0, s, static_cast<const u8*>(d_src), n, block, nblocks, c->models);
+                // 16 blocks per wave, four waves per workgroup, 2 KiB of LDS per block: 128 KiB = one workgroup per CU.
+                // Measured (profiles/r02_sweep_rans.jsonl, RCX_RANS1_LANES): thinner waves on more CUs are SLOWER here
+                // (4096 blocks of 256 KiB: 34 ms with 16 lanes on 64 CUs, 99 ms with 4 lanes on 256 CUs).
+                u32 lanes = 16;
+                if (const char* v = getenv("RCX_RANS1_LANES")) { const int q = atoi(v); if (q == 1 || q == 2 || q == 4 || q == 8 || q == 16) lanes = (u32)q; }
+                const u64 per_wg1 = (u64)lanes * RCX_RANS1_ENC_WAVES;
+                const u32 grid1 = (u32)((nblocks + per_wg1 - 1) / per_wg1);
+                const u32 lds_bytes = lanes * RCX_RANS1_ENC_WAVES * 2048u;
+                if (!c->rans1_lds_set) { // more than the 64 KiB a kernel gets without asking
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rcx_enc_rans1_k), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+                        return RCX_E_HIP;
+                    c->rans1_lds_set = true;
+                }
+                hipLaunchKernelGGL(rcx_enc_rans1_k, dim3(grid1), dim3(64 * RCX_RANS1_ENC_WAVES), lds_bytes, s, static_cast<const u8*>(d_src), n, block,
+                                   nblocks, static_cast<const u32*>(c->models), c->slots, slot, c->sizes, c->starts, c->status, lanes);
+            }
         } else if (static3) {
             const u32 lanes = encode_lanes(c, nblocks);
             const u32 grid = (u32)((nblocks + lanes - 1) / lanes);
@@ -445,9 +470,14 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
         if (coder == RCX_CODER_RANS8)
             hipLaunchKernelGGL(rcx_dec_rans8_k<4>, dim3(grid), dim3(256), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks,
                                block, n, static_cast<u8*>(d_dst), c->status);
-        else
-            hipLaunchKernelGGL(rcx_dec_rans1_k<4>, dim3(grid), dim3(256), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks,
-                               block, n, static_cast<u8*>(d_dst), c->status, c->rans_track ? c->status + 2 : static_cast<u32*>(nullptr));
+        else {
+            const u32 quads = decode_quads(c, nblocks);
+            const u64 per_wg1 = (u64)quads * RCX_QUAD_DEC_WAVES;
+            const u32 grid1 = (u32)((nblocks + per_wg1 - 1) / per_wg1);
+            hipLaunchKernelGGL(rcx_dec_rans1_quad_k<RCX_QUAD_DEC_WAVES>, dim3(grid1), dim3(64 * RCX_QUAD_DEC_WAVES), 0, s,
+                               static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks, block, n, static_cast<u8*>(d_dst), c->status,
+                               quads, c->rans_track ? c->status + 2 : static_cast<u32*>(nullptr));
+        }
         return hipGetLastError() == hipSuccess ? RCX_OK : RCX_E_HIP;
     }
     int r = ensure_divtab(c, block);

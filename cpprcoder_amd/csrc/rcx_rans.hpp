@@ -10,10 +10,11 @@
 // reference writes backwards from the end of its destination, test/main.cpp:384-387); the compacting scatter then
 // takes each stream from where it starts (`starts[]`).
 //
-// Mapping: a block is an octet of lanes, a wave is 8 blocks.  With the eight-state format lane j IS state j, so every
-// lane codes; with the one-state format the octet's lanes all carry the same state (SIMT makes that free) and share
-// the table work (histogram, scaling, the symbol search of the decoder).  The static model lives in LDS per block;
-// nothing is adaptive, so unlike the range coders a block of the eight-state format is 8 chains, not one.
+// Mapping.  The eight-state format: a block is an octet of lanes, lane j IS state j, a wave is 8 blocks -- unlike the
+// range coders, a block is 8 chains here, not one.  The one-state format is one chain per block again: its model is
+// still built by an octet (histogram, scaling), its coding loops run one lane per block (encode) and four lanes per
+// block (decode), see the second half of this file; a single stream (rcx_stream_encode) is coded by one octet whose
+// lanes all carry the state.
 //
 // Included at the end of rcx_kernels.hpp.
 #pragma once
@@ -23,10 +24,7 @@
 
 // LDS of one block while encoding: cum[257] (kept for the header) | table[256] = start | freq << 16 | 64 staged input bytes
 #define RCX_RANS_ENC_LDS_DW (264 + 256 + 16)
-// ... while decoding, one-state format: cum[257] as u16 (+ pad) | first[64] = the symbol holding slot 256*k (the octet
-// scans on from there); eight-state format: see rcx_dec_rans8_k
-#define RCX_RANS_DEC_CUM_BYTES 528
-#define RCX_RANS1_DEC_LDS_BYTES (RCX_RANS_DEC_CUM_BYTES + 64)
+// (the decoders' LDS: see rcx_dec_rans8_k and rcx_dec_rans1_quad_k)
 
 // Lanes of one octet talk through LDS without a barrier: a wave's LDS operations execute in order.  This keeps the
 // compiler from moving or caching LDS accesses across the hand-over (it emits no instruction).
@@ -262,30 +260,6 @@ __global__ __launch_bounds__(256) void rcx_enc_rans_k(const u8* __restrict__ src
 // ===========================================================================
 __device__ __forceinline__ u32 rcx_load_le32(const u8* p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); }
 
-// Reads and checks a block's header; the scaled cumulative counts go to cum16[0..256].  The reference trusts the
-// table (cppans.h:544, :621); a table that is not a scaled cumulative table would send it out of its arrays, so such a
-// block is reported as corrupt instead.  Returns true if the block can be decoded.
-template <u32 PROB_BITS>
-__device__ __forceinline__ bool rcx_rans_read_header(const u8* s, u64 stream_len, u32 len, unsigned short* cum16, u32 j, u32 lane, u32 payload_min)
-{
-    bool good = stream_len >= RCX_RANS_HEADER + payload_min;
-    if (good) good = rcx_load_le32(s) == len; // cppans.h:540-543: the declared size (the layout says len)
-    bool mine_ok = true;
-    if (good) {
-        for (u32 i = j; i < 257; i += 8) { // lane j checks entries j, j+8, ... against their predecessors
-            const u32 v = rcx_load_le32(s + 4 + 4 * i);
-            const u32 before = i == 0 ? 0u : rcx_load_le32(s + 4 * i);
-            if (v > (1u << PROB_BITS) || v < before) mine_ok = false;
-            if (i == 0 && v != 0) mine_ok = false;
-            if (i == 256 && v != (1u << PROB_BITS)) mine_ok = false;
-            cum16[i] = (unsigned short)v;
-        }
-    }
-    const bool all_ok = rcx_octet_ballot(!mine_ok, lane) == 0;
-    rcx_octet_sync();
-    return good && all_ok;
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // The eight-state format: lane j is state j (cppans.h:609-649).
 //
@@ -471,88 +445,290 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_rans8_k(const u8* __restri
     }
 }
 
-// The one-state format (cppans.h:532-564): all lanes of the octet carry the state; the symbol of a slot is found by
-// the octet together: first[k] = the symbol holding slot 256k, and from there eight candidates at a time are tested
-// against their upper bounds (cum2sym of cppans.h:545-550 would be 16 KiB per block).
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void rcx_dec_rans1_k(const u8* __restrict__ comp, u64 comp_size, const u64* __restrict__ offsets,
-                                                             u64 nblocks, u32 block, u64 n, u8* __restrict__ dst, u32* status, u32* track)
+// ===========================================================================
+// The one-state format at speed.  A block is ONE chain here (as with the range coders), so the octet mapping above
+// wastes seven lanes in eight on the coding loop; these kernels are what the block entry points run:
+//   rcx_rans_model_k     the model of every block (count / cumulative / normalize), by octets as above -> `models`
+//   rcx_enc_rans1_k      one lane per block: table lookups in LDS, bytes gathered into dwords, written backwards
+//   rcx_dec_rans1_quad_k 4 lanes per block with the range decoders' machinery (rcx_oct.hpp: table groups, input
+//                        ring): the symbol of a slot = the number of cumulative bounds at or below it, counted in
+//                        two rounds of 16; slot - start is the minimum of the wrapped differences and the frequency
+//                        is minimum - maximum, as in rcx_dec_static_quad_k -- no multiplication at all.
+// ===========================================================================
+#define RCX_RANS_MODEL_DW 776 /* per block in `models`: cum[257] (+ pad to 264) | 256 x {reciprocal, packed} for rcx_enc_rans1_k */
+
+template <u32 PROB_BITS>
+__global__ __launch_bounds__(256) void rcx_rans_model_k(const u8* __restrict__ src, u64 n, u32 block, u64 nblocks, u32* __restrict__ models)
 {
-    __shared__ __attribute__((aligned(16))) u8 lds_all[WAVES * RCX_RANS_BLOCKS * RCX_RANS1_DEC_LDS_BYTES];
+    __shared__ u32 lds_all[4 * RCX_RANS_BLOCKS * RCX_RANS_ENC_LDS_DW];
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const u32 j = lane & 7u, oct = lane >> 3;
-    const u64 blk = ((u64)blockIdx.x * WAVES + wave) * RCX_RANS_BLOCKS + oct;
+    const u64 blk = ((u64)blockIdx.x * 4 + wave) * RCX_RANS_BLOCKS + oct;
+    if (blk >= nblocks) return; // (an octet leaves together)
+    const u64 at = blk * (u64)block;
+    const u32 len = (u32)((n - at) < (u64)block ? (n - at) : (u64)block);
+    u32* cum = lds_all + (wave * RCX_RANS_BLOCKS + oct) * RCX_RANS_ENC_LDS_DW;
+    u32* table = cum + 264;
+    const u8* in = src + at;
+    rcx_rans_model<PROB_BITS>(cum, table, in, len, j, (reinterpret_cast<uintptr_t>(in) & 15u) == 0);
+    u32* out = models + blk * RCX_RANS_MODEL_DW;
+    for (u32 i = j; i < 264; i += 8) out[i] = cum[i];
+    // The encoder's per-symbol constants, the reference's EncSymbol (cppans.h:180-250): q = mulhi(x, rcp) >> shift is
+    // the exact x / freq for every state the encoder holds (Alverson; rcp = ceil(2^(shift+32) / freq) with
+    // shift = ceil(log2 freq) - 1), except freq = 1: rcp = 2^32 - 1, shift = 0 gives q = x - 1 and the bias makes up
+    // for it.  Packed: complement of the frequency | shift << 14 | start << 18.
+    for (u32 sy = j; sy < 256; sy += 8) {
+        const u32 e = table[sy];
+        const u32 freq = e >> 16, start = e & 0xFFFFu;
+        u32 rcp = 0xFFFFFFFFu, shift = 0;
+        if (freq >= 2) {
+            u32 up = 0;
+            while (freq > (1u << up)) ++up;
+            rcp = (u32)(((1ull << (up + 31)) + freq - 1) / freq);
+            shift = up - 1;
+        }
+        out[264 + 2 * sy] = rcp;
+        out[264 + 2 * sy + 1] = ((1u << PROB_BITS) - freq) | (shift << 14) | (start << 18);
+    }
+}
+
+// One lane per block; `lanes_used` of the wave's 64 lanes carry a block (see rcx_api.hip: every SIMD gets a wave before
+// any wave carries 64).  LDS (dynamic, 2 KiB per lane in use): entry s of lane l at 8 * (s * lanes_used + l).
+struct alignas(8) RcxRansSym {
+    u32 rcp, packed; // see rcx_rans_model_k
+};
+// A workgroup is four independent waves (they land one on each SIMD of a CU; single-wave workgroups cluster).
+#define RCX_RANS1_ENC_WAVES 4
+__global__ __launch_bounds__(64 * RCX_RANS1_ENC_WAVES) void rcx_enc_rans1_k(const u8* __restrict__ src, u64 n, u32 block, u64 nblocks,
+                                                                           const u32* __restrict__ models, u8* __restrict__ slots, u64 slot,
+                                                                           u32* __restrict__ sizes, u32* __restrict__ starts, u32* status,
+                                                                           u32 lanes_used)
+{
+    extern __shared__ RcxRansSym rcx_rans1_lds[];
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const bool in_use = lane < lanes_used;
+    const u64 blk = in_use ? ((u64)blockIdx.x * RCX_RANS1_ENC_WAVES + wave) * lanes_used + lane : nblocks;
+    const bool live = blk < nblocks;
+    const u64 at = live ? blk * (u64)block : 0;
+    const u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
+    RcxRansSym* table = rcx_rans1_lds + wave * 256u * lanes_used + (in_use ? lane : 0u);
+    if (live) {
+        const RcxRansSym* m = reinterpret_cast<const RcxRansSym*>(models + blk * RCX_RANS_MODEL_DW + 264);
+        for (u32 sy = 0; sy < 256; ++sy) table[sy * lanes_used] = m[sy];
+    }
+    const u8* in = src + at;
+    u8* const slot_base = slots + (live ? blk : 0) * slot;
+    u32 ptr = (u32)slot;      // byte offset in the slot; everything from here up is written
+    u32 x = 1u << 23;         // cppans.h:260-263
+    u64 acc = 0;              // bytes not yet stored, the newest lowest (it will sit at the lowest address)
+    u32 nacc = 0;             // how many: 0..3 between symbols
+    const u32 floor_ = RCX_RANS_HEADER + 8; // (the stores below are whole dwords)
+    bool overflow = false;
+
+    // One symbol with its constants E in hand (cppans.h:265-287): up to two bytes leave (x < 2^31, x_max >= 2^17), then
+    // x = C(s, x) = x + bias + q * (M - freq), q = x / freq (cppans.h:285-286)
+#define RCX_RANS1_PUT(E)                                                                                \
+    {                                                                                                   \
+        const u32 cmpl_ = (E).packed & 0x3FFFu, shift_ = ((E).packed >> 14) & 15u, start_ = (E).packed >> 18; \
+        const u32 x_max_ = (16384u - cmpl_) << 17;                                                      \
+        const u32 k_ = (x_max_ <= x ? 1u : 0u) + (x_max_ <= (x >> 8) ? 1u : 0u); /* bytes leaving */    \
+        /* they go out lowest first: x & 0xFF, then (x >> 8) & 0xFF; the later one ends up lower */     \
+        const u32 two_ = ((x & 0xFFu) << 8) | ((x >> 8) & 0xFFu);                                       \
+        const u32 out_ = k_ == 2 ? two_ : (x & 0xFFu);                                                  \
+        acc = (acc << (8 * k_)) | (k_ ? out_ : 0u);                                                     \
+        nacc += k_;                                                                                     \
+        x >>= 8 * k_;                                                                                   \
+        /* with 4 or 5 bytes held the four oldest leave as one dword, 4-byte aligned (the slot end is): everything  \
+         * is computed and selected, the store is the only predicated piece */                          \
+        const bool due_ = nacc >= 4;                                                                    \
+        const u32 keep8_ = (8 * nacc) & 8u; /* 8 * (nacc - 4) when due: 0 or 8 */                       \
+        const u32 word_ = (u32)(acc >> keep8_);                                                         \
+        const bool room_ = ptr >= floor_ + 4;                                                           \
+        overflow = overflow || (due_ && !room_);                                                        \
+        ptr -= (due_ && room_) ? 4u : 0u;                                                               \
+        if (due_ && room_) *reinterpret_cast<u32*>(slot_base + ptr) = word_;                            \
+        acc = due_ ? (acc & ((1ull << keep8_) - 1ull)) : acc;                                           \
+        nacc -= due_ ? 4u : 0u;                                                                         \
+        const u32 q_ = __umulhi(x, (E).rcp) >> shift_;                                                  \
+        const u32 bias_ = start_ + (cmpl_ == 16383u ? 16383u : 0u); /* freq = 1: cppans.h:232-234 */     \
+        x = x + bias_ + rcx_mul24(q_, cmpl_);                                                           \
+    }
+
+    if (live) {
+        u32 i = len;
+        const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
+        while (i != 0 && (!aligned || (i & 15u) != 0)) { // the ragged end (and everything, if the block is not aligned)
+            --i;
+            const RcxRansSym e = table[(u32)in[i] * lanes_used];
+            RCX_RANS1_PUT(e);
+        }
+        if (i != 0) {
+            U4 cur = *reinterpret_cast<const U4*>(in + i - 16);
+            RcxRansSym e_next = table[rcx_byte_of(cur, 15) * lanes_used];
+            while (i != 0) {
+                i -= 16;
+                U4 nxt = cur;
+                if (i != 0) nxt = *reinterpret_cast<const U4*>(in + i - 16);
+#pragma unroll
+                for (u32 k = 16; k-- > 0;) {
+                    const RcxRansSym e = e_next; // the next symbol's constants are on their way while this one is coded
+                    e_next = table[(k != 0 ? rcx_byte_of(cur, k - 1) : rcx_byte_of(nxt, 15)) * lanes_used];
+                    RCX_RANS1_PUT(e);
+                }
+                cur = nxt;
+            }
+        }
+        // what is still held, then the state (cppans.h:289-299), then the header (:521-527)
+        for (u32 k = nacc; k-- > 0;) { // oldest first: it sits highest
+            ptr -= 1;
+            slot_base[ptr] = (u8)(acc >> (8 * k));
+        }
+        ptr -= 4;
+        slot_base[ptr] = (u8)x, slot_base[ptr + 1] = (u8)(x >> 8), slot_base[ptr + 2] = (u8)(x >> 16), slot_base[ptr + 3] = (u8)(x >> 24);
+        ptr -= RCX_RANS_HEADER;
+        const u32* cum = models + blk * RCX_RANS_MODEL_DW;
+        u8* h = slot_base + ptr;
+        for (u32 w = 0; w < 258; ++w) {
+            const u32 v = w == 0 ? len : cum[w - 1];
+            h[4 * w] = (u8)v, h[4 * w + 1] = (u8)(v >> 8), h[4 * w + 2] = (u8)(v >> 16), h[4 * w + 3] = (u8)(v >> 24);
+        }
+        sizes[blk] = overflow ? 0u : (u32)slot - ptr;
+        starts[blk] = overflow ? 0u : ptr;
+        if (overflow) rcx_flag(status, RCX_ST_CAPACITY, blk);
+    }
+#undef RCX_RANS1_PUT
+}
+
+// Decode, 4 lanes per block.  LDS per wave: four table groups (rcx_oct.hpp: node n of the four blocks of a group in
+// the four quarters of a 256-byte row) | sixteen input rings.  Node n of a block = its cumulative bounds
+// cum[16n+1 .. 16n+16]; lane j keeps cum[16(4j+1)] .. cum[16(4j+4)] in registers.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void rcx_dec_rans1_quad_k(const u8* __restrict__ comp, u64 comp_size, const u64* __restrict__ offsets,
+                                                                  u64 nblocks, u32 block, u64 n, u8* __restrict__ dst, u32* status,
+                                                                  u32 quads_used, u32* track)
+{
+    __shared__ __attribute__((aligned(256))) u8 lds_all[WAVES * RCX_SQUAD_LDS_BYTES];
+    const u32 lane = threadIdx.x & 63u;
+    const u32 wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u8* lds = lds_all + wave_in_wg * RCX_SQUAD_LDS_BYTES;
+    const u32 j = lane & 3u, quad = lane >> 2;
+    const bool in_use = quad < quads_used; // see rcx_dec_quad_k: the other quads decode along and store nothing
+    const u64 blk = ((u64)blockIdx.x * WAVES + wave_in_wg) * quads_used + (quad & (quads_used - 1u));
     bool live = blk < nblocks;
     const u64 at = live ? blk * (u64)block : 0;
     u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
-    u8* mine = lds_all + (wave * RCX_RANS_BLOCKS + oct) * RCX_RANS1_DEC_LDS_BYTES;
-    unsigned short* cum16 = reinterpret_cast<unsigned short*>(mine);
-    u8* first = mine + RCX_RANS_DEC_CUM_BYTES;
+    const u32 group = 2u * (quad >> 3) + ((0x96u >> (quad & 7u)) & 1u), quarter = (quad & 7u) >> 1;
+    u8* mine = lds + group * RCX_QUAD_GROUP_BYTES + quarter * 64;
+    U4* leaves = reinterpret_cast<U4*>(mine) + j;
+    U4* scratch = reinterpret_cast<U4*>(mine + 16 * 256);
+    u32* block_ring = reinterpret_cast<u32*>(lds + 4 * RCX_QUAD_GROUP_BYTES + quad * RCX_QUAD_RING_BYTES);
 
-    const u8* s = comp;
+    QuadInput in;
     u64 stream_len = 0;
+    u32 U1 = 1, U2 = 2, U3 = 3, U4_ = 16384;
     if (live) {
         const u64 s0 = offsets[blk], s1 = offsets[blk + 1];
         stream_len = s1 - s0;
-        s = comp + s0;
-        bool good = s1 >= s0 && s1 <= comp_size;
-        if (good) good = rcx_rans_read_header<14>(s, stream_len, len, cum16, j, lane, 4);
-        if (!good) {
-            if (j == 0) rcx_flag(status, RCX_ST_CORRUPT, blk);
+        const u8* s = comp + s0;
+        bool good = s1 >= s0 && s1 <= comp_size && stream_len >= RCX_RANS_HEADER + 4;
+        if (good) good = rcx_load_le32(s) == len; // cppans.h:540-543: the declared size (the layout says len)
+        u32 ok = 1;
+        if (good) {
+            // lane j takes cum[64j+1 .. 64j+64] = nodes 4j .. 4j+3; the table must be a scaled cumulative one (the
+            // reference trusts it, cppans.h:544, and would leave its arrays)
+            u32 prev = rcx_load_le32(s + 4 + 4 * (64 * j));
+            if (j == 0 && prev != 0) ok = 0;
+            for (u32 i = 0; i < 64; ++i) {
+                const u32 v = rcx_load_le32(s + 4 + 4 * (64 * j + i + 1));
+                if (v < prev || v > 16384u) ok = 0;
+                reinterpret_cast<u32*>(mine + (4 * j + (i >> 4)) * 256)[i & 15u] = v;
+                if (i == 15) U1 = v;
+                if (i == 31) U2 = v;
+                if (i == 47) U3 = v;
+                if (i == 63) U4_ = v;
+                prev = v;
+            }
+            if (j == 3 && prev != 16384u) ok = 0;
+        }
+        good = good && rcx_quad_or(ok ? 0u : 1u) == 0;
+        if (good) {
+            // QuadInput::begin wants 4 size bytes + 4 state bytes in front of the payload: the state (u32 LE at
+            // 1032) is what it reads big-endian into `low`
+            in.begin(s + RCX_RANS_HEADER - 4, comp + s1, block_ring, scratch + 3);
+        } else {
+            if (j == 0 && in_use) rcx_flag(status, RCX_ST_CORRUPT, blk);
             live = false;
             len = 0;
         }
     }
-    if (live) {
-        // first[k]: the symbol with cum[sym] <= 256k < cum[sym+1]; lane j fills cells j, j+8, ... by walking the table
-        u32 sym = 0;
-        for (u32 k = j; k < 64; k += 8) {
-            while (cum16[sym + 1] <= 256u * k) ++sym; // cum[256] = 2^14 > 256k: ends
-            first[k] = (u8)sym;
-        }
+    if (!live) {
+        in.idle(comp, block_ring, scratch + 3);
+        U1 = 1, U2 = 2, U3 = 3, U4_ = 16384;
+        U4 v;
+        v.x = v.y = v.z = v.w = 16384;
+        for (u32 q = 0; q < 16; ++q) leaves[q * 16] = v;
     }
-    rcx_octet_sync();
-    const u8* const comp_end = comp + comp_size;
-    u32 x = live ? rcx_load_le32(s + RCX_RANS_HEADER) : (1u << 23); // cppans.h:303-310
-    u64 rp = RCX_RANS_HEADER + 4;                                    // the next payload byte, as an offset in the stream
+    u32 x = live ? rcx_bswap(in.low) : (1u << 23); // cppans.h:303-310
+    const u32 maxlen = rcx_wave_max(len);
+    const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
     u8* out = dst + at;
-    const u32 max_len = rcx_wave_max(len);
-    bool ran_dry = false;
-    for (u32 i = 0; i < max_len; ++i) {
-        const bool on = i < len;
-        // the next two bytes, asked for before the search (never past the compressed buffer)
-        const u8* ra = s + rp;
-        const u32 b0 = live && ra < comp_end ? ra[0] : 0u, b1 = live && ra + 1 < comp_end ? ra[1] : 0u;
-        const u32 slot_ = x & 16383u; // cppans.h:313-316
-        u32 sym = first[on ? (slot_ >> 8) : 0u];
-        // the octet tests candidates sym + j: the symbol is the first whose upper bound lies above the slot
-        for (;;) { // (octets leave this loop one by one: the lanes of an octet always agree)
-            const u32 c = sym + j;
-            const bool hit = !on || (c < 256u && cum16[c + 1] > slot_);
-            const u32 m = rcx_octet_ballot(hit, lane);
-            if (m != 0) {
-                sym += (u32)__ffs((int)m) - 1;
-                break;
+    const bool leader = live && in_use && j == 0;
+    const u32 leaves_lds = (u32)reinterpret_cast<uintptr_t>(leaves);
+
+    // One symbol (cppans.h:556-561): get, the symbol of the slot, advance, renormalise by at most two bytes
+#define RCX_RANS1_SYMBOL(SYM)                                                                                \
+    {                                                                                                        \
+        const u32 slot_ = x & 16383u;                                                                        \
+        const u32 d1_ = slot_ - U1, d2_ = slot_ - U2, d3_ = slot_ - U3, d4_ = slot_ - U4_;                   \
+        const u32 c1_ = (U1 <= slot_ ? 1u : 0u) + (U2 <= slot_ ? 1u : 0u) + (U3 <= slot_ ? 1u : 0u) + (U4_ <= slot_ ? 1u : 0u); \
+        const u32 node_ = rcx_quad_sum(c1_);                                                                 \
+        const u32 rem_ = rcx_quad_min(rcx_umin(rcx_umin(rcx_umin(d1_, d2_), rcx_umin(d3_, d4_)), slot_));    \
+        const RcxV4 l_ = *reinterpret_cast<const RcxLdsV4*>(leaves_lds + (node_ << 8));                      \
+        const u32 e1_ = slot_ - l_.x, e2_ = slot_ - l_.y, e3_ = slot_ - l_.z, e4_ = slot_ - l_.w;            \
+        const u32 c2_ = (l_.x <= slot_ ? 1u : 0u) + (l_.y <= slot_ ? 1u : 0u) + (l_.z <= slot_ ? 1u : 0u) + (l_.w <= slot_ ? 1u : 0u); \
+        const u32 pos_ = rcx_quad_sum(c2_);                                                                  \
+        const u32 lo_ = rcx_quad_min(rcx_umin(rcx_umin(rcx_umin(e1_, e2_), rcx_umin(e3_, e4_)), rem_));      \
+        const u32 hi_ = rcx_quad_max(rcx_umax(rcx_umax(e1_, e2_), rcx_umax(e3_, e4_)));                      \
+        (SYM) = (node_ << 4) + pos_;                                                                         \
+        x = rcx_mul24(lo_ - hi_, x >> 14) + lo_; /* freq * (x >> 14) + slot - start (cppans.h:326) */        \
+        const u32 r8_ = x < (1u << 15) ? 16u : (x < (1u << 23) ? 8u : 0u); /* cppans.h:328-332 */            \
+        x = (u32)(((((u64)x) << 32) | in.n4) << r8_ >> 32);                                                  \
+        in.bp8 += r8_;                                                                                       \
+        in.fetch_pair();                                                                                     \
+        in.n4 = rcx_bswap(rcx_funnel_shr(in.w1, in.w0, in.bp8));                                             \
+    }
+
+    if (full) {
+        for (u32 i0 = 0; i0 < maxlen; i0 += 16) {
+            in.topup();
+            u32 w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (u32 k = 0; k < 16; ++k) {
+                u32 sym;
+                RCX_RANS1_SYMBOL(sym);
+                w[k >> 2] |= sym << (8 * (k & 3));
             }
-            sym += 8;
+            if (leader) {
+                U4 o;
+                o.x = w[0], o.y = w[1], o.z = w[2], o.w = w[3];
+                *reinterpret_cast<U4*>(out + i0) = o;
+            }
         }
-        if (on) {
-            const u32 lo = cum16[sym], hi = cum16[sym + 1];
-            if (j == 0) out[i] = (u8)sym;
-            x = (hi - lo) * (x >> 14) + slot_ - lo; // cppans.h:326
-            // cppans.h:328-332: at most two bytes come in (x >= 2^9 after the step)
-            if (x < (1u << 23)) {
-                x = (x << 8) | b0;
-                rp += 1;
-                if (x < (1u << 23)) {
-                    x = (x << 8) | b1;
-                    rp += 1;
-                }
+    } else {
+        for (u32 i = 0; i < maxlen; ++i) {
+            if ((i & 15u) == 0) in.topup();
+            if (i < len) { // the 4 lanes of a quad agree
+                u32 sym;
+                RCX_RANS1_SYMBOL(sym);
+                if (leader) out[i] = (u8)sym;
             }
-            if (rp > stream_len) ran_dry = true;
         }
     }
-    if (live && j == 0 && ran_dry) rcx_flag(status, RCX_ST_CORRUPT, blk);
+#undef RCX_RANS1_SYMBOL
+    // a valid stream holds every byte that was taken
+    const u64 taken = RCX_RANS_HEADER - 4 + in.taken(); // QuadInput counts from 8 bytes into what it was given
+    if (leader && taken > stream_len) rcx_flag(status, RCX_ST_CORRUPT, blk);
     // the single-stream call wants what rANS::decode returns: the payload bytes consumed (cppans.h:562)
-    if (track && live && j == 0 && blk == 0) track[0] = (u32)(rp - RCX_RANS_HEADER);
+    if (track && leader && blk == 0) track[0] = (u32)(taken - RCX_RANS_HEADER);
 }
+
