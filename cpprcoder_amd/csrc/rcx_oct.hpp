@@ -313,8 +313,21 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
     if (!live) in.idle(comp, block_ring, parked + 3);
 
     const u32 maxlen = rcx_wave_max(len);
-    const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
     u8* out = dst + at;
+    // The fast loop (16 symbols at a go, no per-symbol length test, 16-byte stores) runs as far as every block of the
+    // wave has whole groups of 16 and its output is 16-byte aligned; the rest -- the ragged end of a buffer's last
+    // block, the whole wave if an output is unaligned -- is decoded symbol by symbol behind it.
+    u32 fast_end;
+    {
+        u32 mine = live ? (len & ~15u) : 0xFFFFFFF0u; // (a quad without a block sets no limit)
+        if (live && (reinterpret_cast<uintptr_t>(out) & 15u) != 0) mine = 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const u32 other = (u32)__shfl_xor((int)mine, o, 64);
+            mine = mine < other ? mine : other;
+        }
+        fast_end = mine == 0xFFFFFFF0u ? 0u : mine;
+    }
     const bool leader = live && in_use && j == 0;
 
     // One symbol; the owning lane ORs it into WORD at bit SHIFT (the quad's other lanes OR in 0).
@@ -458,7 +471,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
         stage[lane % RCX_QUAD_STAGE] = q_; /* four lanes per entry, same value */                          \
     }
 #define RCX_QUAD_STAGE_GET(I0) ahead = divtab[(I0) + RCX_QUAD_STAGE + lane % RCX_QUAD_STAGE];
-    if (full) {
+    {
         // 64 decoded bytes leave as four back-to-back 16-byte stores, so that L2 sees whole 64-byte pieces
         // (16-byte pieces 16 symbols apart were written to HBM one by one: 4x WRITE_SIZE).  Groups 0..2 wait
         // in the block's scratch area, group 3 in registers, and the stores are issued right AFTER the next
@@ -468,7 +481,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
 #if defined(RCX_STAMP_DEC)
         unsigned long long stamp_sum_[4] = {0, 0, 0, 0};
 #endif
-        for (u32 i0 = 0; i0 < maxlen; i0 += 16) {
+        for (u32 i0 = 0; i0 < fast_end; i0 += 16) {
             RCX_QUAD_STAGE_PUT();
             in.topup();
             RCX_QUAD_STAGE_GET(i0);
@@ -524,16 +537,17 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
         if (blockIdx.x == 7 && threadIdx.x == 0)
             for (int i_ = 0; i_ < 4; ++i_) rcx_dec_stamp_out[i_] = stamp_sum_[i_];
 #endif
-        if (leader && maxlen != 0) { // what is still parked: the last 16..64 bytes of the block
-            const u32 groups = ((maxlen - 1) >> 4 & 3u) + 1;
-            U4* o4 = reinterpret_cast<U4*>(out + ((maxlen - 1) & ~63u));
+        if (leader && fast_end != 0) { // what is still parked: the last 16..64 bytes of the fast region
+            const u32 groups = ((fast_end - 1) >> 4 & 3u) + 1;
+            U4* o4 = reinterpret_cast<U4*>(out + ((fast_end - 1) & ~63u));
             o4[0] = parked[0];
             if (groups > 1) o4[1] = parked[1];
             if (groups > 2) o4[2] = parked[2];
             if (groups > 3) o4[3] = o_last;
         }
-    } else {
-        for (u32 i = 0; i < maxlen; ++i) {
+    }
+    {
+        for (u32 i = fast_end; i < maxlen; ++i) { // (fast_end is a multiple of 16: the top-ups stay 16 symbols apart)
             if ((i & 15u) == 0) {
                 RCX_QUAD_STAGE_PUT();
                 in.topup();
@@ -771,6 +785,8 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
             if (FULL) {
                 piece = piece_ahead;
                 if (k + 1 < nchunks) piece_ahead = *reinterpret_cast<const U4*>(in + i0 + RCX_MC_CHUNK);
+            } else if (i0 + RCX_MC_CHUNK <= len && (reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
+                piece = *reinterpret_cast<const U4*>(in + i0); // a whole, aligned chunk of a ragged block (or of a single stream)
             } else {
                 u32 w[4] = {0, 0, 0, 0};
                 for (u32 s = 0; s < RCX_MC_CHUNK; ++s)

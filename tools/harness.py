@@ -23,19 +23,22 @@ def main():
     files = workloads.canterbury_files()
     ctx = rcx.Context(0)
     ctx.stream_encode(b"warm up")
-    print("Adaptive Range Coder, one stream per file (rcx_stream_encode / rcx_stream_decode)")
-    print("|file|bytes|compressed|ratio|encode us|decode us|round trip|")
-    print("|:---|---:|---:|---:|---:|---:|:---|")
-    for name in workloads.CANTERBURY_ORDER:
-        data = files[name]
-        t0 = time.perf_counter()
-        st, rq, comp = ctx.stream_encode(data)
-        t1 = time.perf_counter()
-        st2, rq2, back = ctx.stream_decode(comp, len(data))
-        t2 = time.perf_counter()
-        ok = st == 0 and st2 == 0 and back == data
-        print(f"|{name}|{len(data)}|{len(comp)}|{len(comp) / len(data):.6f}|{(t1 - t0) * 1e6:.0f}|{(t2 - t1) * 1e6:.0f}|{'ok' if ok else 'MISMATCH'}|")
-    print()
+    # test/main.cpp:253-302 (run_rangecoder), :304-364 (run_adaptive), :366-456 (run_ans), :458-546 (run_ans_simd)
+    for title, coder in (("Adaptive Range Coder", rcx.CODER_ADAPTIVE), ("Range Coder (static)", rcx.CODER_STATIC),
+                         ("rANS", rcx.CODER_RANS), ("rANS SIMD (rANS::encode_simd / decode_simd)", rcx.CODER_RANS8)):
+        print(f"{title}, one stream per file (rcx_stream_encode / rcx_stream_decode)")
+        print("|file|bytes|compressed|ratio|encode us|decode us|round trip|")
+        print("|:---|---:|---:|---:|---:|---:|:---|")
+        for name in workloads.CANTERBURY_ORDER:
+            data = files[name]
+            t0 = time.perf_counter()
+            st, rq, comp = ctx.stream_encode(data, coder=coder)
+            t1 = time.perf_counter()
+            st2, rq2, back = ctx.stream_decode(comp, len(data), coder=coder)
+            t2 = time.perf_counter()
+            ok = st == 0 and st2 == 0 and back == data
+            print(f"|{name}|{len(data)}|{len(comp)}|{len(comp) / len(data):.6f}|{(t1 - t0) * 1e6:.0f}|{(t2 - t1) * 1e6:.0f}|{'ok' if ok else 'MISMATCH'}|")
+        print()
     print("Same files as independent 4 KiB blocks (rcx_encode_blocks / rcx_decode_blocks, host buffers incl. PCIe copies)")
     print("|file|bytes|compressed|ratio|encode us|decode us|round trip|")
     print("|:---|---:|---:|---:|---:|---:|:---|")
