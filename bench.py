@@ -66,23 +66,23 @@ def baseline_config(name: str, n: int, block: int, world: int) -> str:
     return "none of BASELINE.json's configs (a variation for diagnosis)"
 
 
-def cpu_baseline(data: np.ndarray, block: int):
+def cpu_baseline(data: np.ndarray, block: int, coder: int = 0):
     """The reference's CPU coder on a bounded sample of the same bytes the GPU coded, all host cores."""
     import oracle_lib
     oracle_lib.build_oracle()
     chk = oracle_lib.reference() or oracle_lib.oracle()
     cores = os.cpu_count() or 1
     t0 = time.time()
-    slots, sizes = chk.encode_blocks(data, block, threads=cores)
+    slots, sizes = chk.encode_blocks(data, block, coder=coder, threads=cores)
     t1 = time.time()
-    back, ok = chk.decode_blocks(slots, sizes, block, len(data), threads=cores)
+    back, ok = chk.decode_blocks(slots, sizes, block, len(data), coder=coder, threads=cores)
     t2 = time.time()
     assert ok and np.array_equal(back, data)
     one = data[: min(len(data), 8 << 20)]
     s0 = time.time()
-    s_slots, s_sizes = chk.encode_blocks(one, block, threads=1)
+    s_slots, s_sizes = chk.encode_blocks(one, block, coder=coder, threads=1)
     s1 = time.time()
-    chk.decode_blocks(s_slots, s_sizes, block, len(one), threads=1)
+    chk.decode_blocks(s_slots, s_sizes, block, len(one), coder=coder, threads=1)
     s2 = time.time()
     mb = len(data) / 1e6
     return {
@@ -118,6 +118,8 @@ def main() -> None:
                     help="default: uniform on one GPU (BASELINE.json configs[1]), zipf on several (configs[3])")
     ap.add_argument("--bytes", type=int, default=1 << 30, help="uncompressed bytes per GPU")
     ap.add_argument("--block", type=int, default=BLOCK)
+    ap.add_argument("--coder", default="adaptive", choices=["adaptive", "static", "rans", "rans8"],
+                    help="adaptive (BASELINE.json's metric) | static | rans | rans8: the same protocol on the sibling coders (diagnosis; not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=256)
     ap.add_argument("--exchange", action="store_true",
@@ -149,12 +151,13 @@ def main() -> None:
     if args.workload is None:
         args.workload = "uniform" if world == 1 else "zipf"
     n, block = args.bytes, args.block
+    coder = ("adaptive", "static", "rans", "rans8").index(args.coder)
     nblocks = rcx.block_count(n, block)
     seed = 12345 + rank  # mt19937(12345 + rank) per shard
     src, host_src, gen_s = make_workload(args.workload, n, seed, device)
     ctx = rcx.Context(local)
-    ctx.reserve(n, block)
-    bound = rcx.encode_bound(n, block)
+    ctx.reserve(n, block, coder)
+    bound = rcx.encode_bound(n, block, coder)
     # Two compressed buffers: with the exchange on, step i+1 encodes into the other one while the exchange of
     # step i is still reading this one (the exchange of a step overlaps its own decode AND the next step's encode).
     nbuf = 2 if exchange else 1
@@ -177,11 +180,11 @@ def main() -> None:
         comp, offs = comps[b], offss[b]
         if released[b] is not None:
             main_stream.wait_event(released[b])
-        ctx.encode_blocks_device(src, block, comp, offs)
+        ctx.encode_blocks_device(src, block, comp, offs, coder=coder)
         if exchange:
             side.wait_stream(main_stream)  # the exchange starts when the encode is done (and queues behind the previous one)
         # the decoder takes the block table from HBM: no host round trip between encode and decode
-        ctx.decode_blocks_device(comp, bound, offs, n, block, out)
+        ctx.decode_blocks_device(comp, bound, offs, n, block, out, coder=coder)
         if exchange:
             # one call: sizes all-gather (its one host sync waits for the encode only), then every segment and table
             # part point to point straight into place -- while the decode above runs on the main stream
@@ -238,6 +241,8 @@ def main() -> None:
         roundtrip_ok = roundtrip_ok and int(table[block_base[-1]]) == seg_base[-1]
 
     if rank == 0:
+        workload_origin = ("the 11 Canterbury files concatenated and tiled" if args.workload == "canterbury"
+                           else f"std::mt19937({seed if world == 1 else '12345 + rank'})")
         ms_step = wall * 1e3 / args.steps
         enc_ms = timing["encode"]["ms"] / max(1, timing["encode"]["launches"])
         dec_ms = timing["decode"]["ms"] / max(1, timing["decode"]["launches"])
@@ -246,6 +251,9 @@ def main() -> None:
         auto = "rcx_dec_quad_k"  # rcx_api.hip: decode_lanes()
         dec_name = {"1": "rcx_dec_adaptive_k", "4": "rcx_dec_quad_k", "8": "rcx_dec_oct_k"}.get(os.environ.get("RCX_LANES_PER_BLOCK", ""), auto)
         enc_name = {"0": "rcx_enc_adaptive_k", "1": "rcx_enc_oct_k", "2": "rcx_enc_mc_k"}.get(os.environ.get("RCX_ENC_VARIANT", ""), "rcx_enc_mc5_k")
+        if coder != 0:  # (kernel names of the sibling coders, rcx_api.hip)
+            enc_name = {1: "rcx_enc_static3_k", 2: "rcx_enc_rans1_k", 3: "rcx_enc_rans_k"}[coder]
+            dec_name = {1: "rcx_dec_static_quad_k", 2: "rcx_dec_rans1_quad_k", 3: "rcx_dec_rans8_k"}[coder]
         dom, dom_ms = (dec_name, dec_ms) if dec_ms >= enc_ms else (enc_name, enc_ms)
         algo_bytes = (1.0 + ratio) * n  # 1 read + r write per input byte (or r read + 1 write)
         achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
@@ -271,9 +279,11 @@ def main() -> None:
             "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"{n >> 20} MiB synthetic {args.workload} bytes per GPU (std::mt19937({seed if world == 1 else '12345 + rank'})), "
+            "config": {"workload": f"{n >> 20} MiB synthetic {args.workload} bytes per GPU ({workload_origin}), "
                                    f"{block >> 10} KiB blocks, encode+decode round trip resident in HBM",
-                       "baseline_config": baseline_config(args.workload, n, block, world),
+                       "baseline_config": baseline_config(args.workload, n, block, world) if coder == 0 else
+                                          f"none of BASELINE.json's configs: the {args.coder} coder (cppans.h / RangeEncoder) on that shape",
+                       "coder": args.coder,
                        "bytes_per_gpu": n, "block": block, "blocks_per_gpu": nblocks,
                        "parallelism": f"blocks sharded over {world} GPU(s), one process per GPU"
                                       + ("; rcx_allgatherv_segments (RCCL send/recv straight into place) overlapped with the decode and with the next step's encode" if exchange else "")},
@@ -299,7 +309,7 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             try:
                 sample = host_src[: min(n, args.cpu_sample_mib << 20) // block * block or n]
-                cb, cpu_sizes = cpu_baseline(sample, block)
+                cb, cpu_sizes = cpu_baseline(sample, block, coder)
                 line["cpu_baseline"] = cb
                 line["gpu_over_cpu"] = round(line["value"] / cb["value"], 1)
                 # same bytes on both sides: the GPU's per-block stream sizes must be the CPU coder's

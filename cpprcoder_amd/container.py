@@ -2,13 +2,13 @@
 
 The reference has no multi-block format (one stream per file, test/main.cpp:304-364); this is the framing the
 block engine needs to be usable on files.  Every block's stream inside is bit-exact what the reference's
-AdaptiveRangeEncoder (or RangeEncoder, coder = 1) emits for that block, so a reader with only the reference
-can decode a container block by block.
+AdaptiveRangeEncoder (or RangeEncoder, coder = 1; rANS::encode, coder = 2; rANS::encode_simd, coder = 3) emits
+for that block, so a reader with only the reference can decode a container block by block.
 
 Layout (little-endian):
     0   4  magic  b"RCXB"
     4   1  version (1)
-    5   1  coder   (0 adaptive, 1 static)
+    5   1  coder   (0 adaptive, 1 static, 2 rANS one state, 3 rANS eight states: include/rcx.h RCX_CODER_*)
     6   2  reserved (0)
     8   4  block size in bytes
     12  8  n, the original size
@@ -48,7 +48,7 @@ def parse(blob):
     magic, version, coder, reserved, block, n, nblocks = _FIXED.unpack(bytes(buf[: _FIXED.size]))
     if magic != MAGIC:
         raise ContainerError("not an RCXB container")
-    if version != VERSION or coder not in (0, 1) or reserved != 0:
+    if version != VERSION or coder not in (0, 1, 2, 3) or reserved != 0:
         raise ContainerError("unsupported container version or coder")
     if block < 16 or block > (1 << 24) - 256 or nblocks != (n + block - 1) // block:
         raise ContainerError("inconsistent header")

@@ -27,7 +27,7 @@ def test_header_round_trip_and_rejections():
     with pytest.raises(container.ContainerError):
         container.header_bytes(0, 4096, 5 * 4096, offs)  # wrong block count
     bad = bytearray(blob)
-    bad[5] = 7                                          # unknown coder
+    bad[5] = 7                                          # unknown coder (0..3 are include/rcx.h's RCX_CODER_*)
     with pytest.raises(container.ContainerError):
         container.parse(bytes(bad))
     empty = container.parse(container.header_bytes(1, 65536, 0, np.zeros(1, np.uint64)))
@@ -39,7 +39,7 @@ def test_pack_unpack_and_blocks_are_the_references(oracle):
     from cpprcoder_amd import rcx, workloads
     ctx = rcx.Context(0)
     try:
-        for coder in (0, 1):
+        for coder in (0, 1, 2, 3):
             for n, block in ((0, 65536), (1, 4096), (300_001, 4096), (2_000_000, 65536)):
                 data = workloads.zipf(n, 3 + n % 7) if n else np.zeros(0, np.uint8)
                 blob = container.pack(data, block, coder, ctx)
@@ -69,5 +69,7 @@ def test_cli_round_trip(tmp_path):
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "back.bin").read_bytes() == src.read_bytes()
     r = run("t", "--static", str(src))
+    assert r.returncode == 0 and "MISMATCH" not in r.stdout, r.stdout + r.stderr
+    r = run("t", "--coder", "rans8", "-b", "16384", str(src))
     assert r.returncode == 0 and "MISMATCH" not in r.stdout, r.stdout + r.stderr
     assert (tmp_path / "out.rcxb").stat().st_size < 0.6 * src.stat().st_size
