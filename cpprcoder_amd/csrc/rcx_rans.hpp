@@ -176,40 +176,73 @@ __global__ __launch_bounds__(256) void rcx_enc_rans_k(const u8* __restrict__ src
     const u32 floor_ = RCX_RANS_HEADER + (WORD ? 32u : 4u);
     bool overflow = false;
 
-    // rounds of 8 symbols, from the end of the block: the octet stages symbols [8r, 8r+8) in LDS (lane j brings byte j)
+    // rounds of 8 symbols, from the end of the block
     const u32 rounds = (len + 7) >> 3;
     u32 next_byte = 0;
     if (rounds != 0) {
         const u32 i = 8 * (rounds - 1) + j;
         next_byte = i < len ? in[i] : 0u;
     }
-    for (u32 r = rounds; r-- > 0;) {
-        rcx_octet_sync();
-        stage[j] = (u8)next_byte;
-        rcx_octet_sync();
-        if (r != 0) next_byte = in[8 * (r - 1) + j]; // the next round's byte is on its way while this one is coded
-        const u32 have = (len - 8 * r) < 8u ? (len - 8 * r) : 8u; // symbols in this round (only the last one is short)
-        if (WORD) {
-            // cppans.h:591-594: symbol i goes to state i & 7 = lane j; the eight puts of a round are independent but
-            // for the order of their words: written backwards in the order 7 .. 0, i.e. ascending by lane in memory
-            const bool active = live && j < have;
-            const u32 e = table[stage[j]];
-            const u32 freq = e >> 16, start = e & 0xFFFFu;
-            const u32 x_max = freq << 20; // cppans.h:357: ((2^16 >> 12) << 16) * freq in u32 -- wraps to 0 for freq = 4096
-            const bool emit = active && x_max <= x;
-            const u32 mask = rcx_octet_ballot(emit, lane);
-            const u32 words = (u32)__popc(mask), before = (u32)__popc(mask & ((1u << j) - 1u));
-            if (ptr < floor_ + 2 * words) overflow = true;
-            else ptr -= 2 * words;
-            if (emit && !overflow) *reinterpret_cast<unsigned short*>(slot_base + ptr + 2 * before) = (unsigned short)(x & 0xFFFFu);
-            if (emit) x >>= 16;
-            if (active) { // cppans.h:363
-                u32 rem;
-                const u32 q = rcx_div_small_quotient(x, freq, rem);
-                x = (q << 12) + rem + start;
-            }
-        } else {
-            // cppans.h:516-519: one state; every lane of the octet carries it, lane 0 stores
+    if (WORD) {
+        // cppans.h:591-594: symbol i goes to state i & 7 = lane j, so every lane codes the byte it loaded itself.  The eight
+        // puts of a round are independent but for the order of their words: written backwards in the order 7 .. 0, i.e.
+        // ascending by lane in memory -- an octet ballot gives every emitting lane its place.
+#define RCX_RANS8_PUT(ACTIVE, SYM)                                                                                   \
+    {                                                                                                                \
+        const u32 e_ = table[(SYM)];                                                                                 \
+        const u32 freq_ = e_ >> 16, start_ = e_ & 0xFFFFu;                                                           \
+        const u32 x_max_ = freq_ << 20; /* cppans.h:357: ((2^16 >> 12) << 16) * freq in u32 -- wraps to 0 for freq = 4096 */ \
+        const bool emit_ = (ACTIVE) && x_max_ <= x;                                                                  \
+        const u32 mask_ = rcx_octet_ballot(emit_, lane);                                                             \
+        const u32 words_ = (u32)__popc(mask_), before_ = (u32)__popc(mask_ & ((1u << j) - 1u));                      \
+        const bool room_ = ptr >= floor_ + 2 * words_;                                                               \
+        overflow = overflow || !room_;                                                                               \
+        ptr -= room_ ? 2 * words_ : 0u;                                                                              \
+        if (emit_ && !overflow) *reinterpret_cast<unsigned short*>(slot_base + ptr + 2 * before_) = (unsigned short)(x & 0xFFFFu); \
+        x = emit_ ? x >> 16 : x;                                                                                     \
+        u32 rem_;                                                                                                    \
+        const u32 q_ = rcx_div_small_quotient(x, freq_ ? freq_ : 1u, rem_); /* cppans.h:363 */                       \
+        x = (ACTIVE) ? (q_ << 12) + rem_ + start_ : x;                                                               \
+    }
+        u32 r = rounds;
+        if (r != 0) { // the block's last round: it may be short
+            --r;
+            const u32 have = len - 8 * r;
+            const u32 sym = next_byte;
+            next_byte = in[r != 0 ? 8 * (r - 1) + j : j];
+            RCX_RANS8_PUT(live && j < have, sym);
+        }
+        // whole rounds, as many as every block of the wave still has: no tests for a block that has ended
+        u32 common = live ? r : 0xFFFFFFFFu;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const u32 other = (u32)__shfl_xor((int)common, o, 64);
+            common = common < other ? common : other;
+        }
+        if (common == 0xFFFFFFFFu) common = 0;
+        if (!live) r = common; // (an octet without a block steps along, reading the start of the buffer; it stores nothing)
+        for (u32 t = 0; t < common; ++t) {
+            --r;
+            const u32 sym = next_byte;
+            next_byte = in[r != 0 ? 8 * (r - 1) + j : j]; // the next round's byte is on its way while this one is coded
+            RCX_RANS8_PUT(live, sym);
+        }
+        while (r != 0) { // blocks longer than the wave's shortest
+            --r;
+            const u32 sym = next_byte;
+            next_byte = in[r != 0 ? 8 * (r - 1) + j : j];
+            RCX_RANS8_PUT(live, sym);
+        }
+#undef RCX_RANS8_PUT
+    } else {
+        // cppans.h:516-519: one state; every lane of the octet carries it, lane 0 stores; the octet stages symbols
+        // [8r, 8r+8) in LDS (lane j brings byte j)
+        for (u32 r = rounds; r-- > 0;) {
+            rcx_octet_sync();
+            stage[j] = (u8)next_byte;
+            rcx_octet_sync();
+            if (r != 0) next_byte = in[8 * (r - 1) + j]; // the next round's byte is on its way while this one is coded
+            const u32 have = (len - 8 * r) < 8u ? (len - 8 * r) : 8u; // symbols in this round (only the last one is short)
             for (u32 k = have; k-- > 0;) {
                 const u32 e = table[stage[k]];
                 const u32 freq = e >> 16, start = e & 0xFFFFu;
@@ -358,7 +391,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_rans8_k(const u8* __restri
         U4 z;
         z.x = z.y = z.z = z.w = 0;
         if (!live || a >= comp_end) return z;
-        if (a + 16 <= comp_end) return *reinterpret_cast<const U4*>(a);
+        if (__builtin_expect(a + 16 <= comp_end, 1)) return *reinterpret_cast<const U4*>(a);
         u32 w[4] = {0, 0, 0, 0}; // the buffer's last, partial piece
         for (u32 k = 0; a + k < comp_end; ++k) w[k >> 2] |= (u32)a[k] << (8 * (k & 3));
         z.x = w[0], z.y = w[1], z.z = w[2], z.w = w[3];
@@ -382,7 +415,54 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_rans8_k(const u8* __restri
     const bool out8 = (reinterpret_cast<uintptr_t>(out) & 7u) == 0;
     const u32 groups = len >> 3;
     const u32 max_groups = rcx_wave_max(groups);
-    for (u32 g = 0; g < max_groups; ++g) {
+    // The fast loop: as many steps (a multiple of 8) as every block of the wave has, words aligned, output 8-byte
+    // aligned -- no per-step tests for a block that has ended, no unaligned paths; one wave-uniform branch for the
+    // ring's refill.  Whatever is left (the ragged end of a buffer's last block, odd alignments) takes the loop below.
+    u32 fast_groups;
+    {
+        u32 mine = live ? (groups & ~7u) : 0xFFFFFFF8u; // (an octet without a block sets no limit)
+        if (live && !out8) mine = 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const u32 other = (u32)__shfl_xor((int)mine, o, 64);
+            mine = mine < other ? mine : other;
+        }
+        fast_groups = (mine == 0xFFFFFFF8u || !even) ? 0u : mine;
+    }
+    for (u32 g = 0; g < fast_groups; ++g) {
+        if (rcx_any(live && (pending || p + 128 >= filled))) { // some octet has a piece to put into its ring, or to ask for
+            if (pending) {
+                *reinterpret_cast<U4*>(ring + ((filled + 16 * j) & (RCX_R8_RING_BYTES - 1))) = pend;
+                filled += 128;
+            }
+            pending = live && p + 128 >= filled;
+            if (pending) pend = load16(filled);
+        }
+        // cppans.h:636-639 (simdDecSym :412-440)
+        const u32 slot_ = x & 4095u;
+        const u32 f = first[slot_ >> 2];
+        const u32 e0 = table[f], e1 = table[f + 1], e2 = table[f + 2], e3 = table[f + 3];
+        u32 e = e0;
+        if ((e1 & 4095u) <= slot_) e = e1;
+        if ((e2 & 4095u) <= slot_) e = e2;
+        if ((e3 & 4095u) <= slot_) e = e3;
+        obuf[8 * (g & 7u) + j] = (u8)(e >> 24);
+        x = (((e >> 12) & 4095u) + 1u) * (x >> 12) + slot_ - (e & 4095u); // freq * (x >> 12) + bias
+        // cppans.h:640-641 (simdDecRenorm :443-488): the states below 2^16 take one word each, in state order
+        const bool need = x < (1u << 16);
+        const u32 mask = rcx_octet_ballot(need, lane);
+        const u32 o = (p + 2 * (u32)__popc(mask & ((1u << j) - 1u))) & (RCX_R8_RING_BYTES - 1);
+        const u32 word = *reinterpret_cast<const unsigned short*>(ring + o);
+        x = need ? ((x << 16) | word) : x;
+        p += 2 * (u32)__popc(mask);
+        if ((g & 7u) == 7u) { // eight steps = 64 symbols of the block: 8 bytes per lane
+            rcx_octet_sync();
+            const u64 eight = *reinterpret_cast<const u64*>(obuf + 8 * j);
+            if (live) *reinterpret_cast<u64*>(out + 8 * (g - 7) + 8 * j) = eight;
+            rcx_octet_sync();
+        }
+    }
+    for (u32 g = fast_groups; g < max_groups; ++g) {
         const bool on = g < groups;
         // the 128 bytes asked for in the previous step go into the half of the ring that has been used up
         if (pending) {
