@@ -672,8 +672,18 @@ int rcx_stream_encode(rcx_ctx* c, int coder, const uint8_t* src, uint32_t n,
     if (coder == RCX_CODER_STATIC) {
         // RangeEncoder<T>::encode (cpprcoder.h:375-458) returns a bool; the caller (the facade) replays the
         // sink calls itself, so the whole stream is handed back: RCX_OK, or RCX_E_CAPACITY if dst is too small.
-        hipLaunchKernelGGL(rcx_enc_static_k, dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)n, block, (u64)1, c->slots, slot,
-                           c->sizes, c->status, static_cast<const u32*>(nullptr));
+        if (c->enc_variant >= 2 && n >= RCX_MIN_BLOCK && n <= RCX_MAX_BLOCK) {
+            // one chain runs faster through the three-wave encoder (table lookups / arithmetic / writer on three SIMDs)
+            // than on a lone lane; the one-wave kernel behind it takes over if a carry outran the rings
+            if ((r = ensure_redo(c, 1)) != RCX_OK) return r;
+            hipLaunchKernelGGL(rcx_enc_static3_k, dim3(1), dim3(RCX_ST3_THREADS), 0, nullptr, c->h_in, (u64)n, block, (u64)1, c->slots, slot,
+                               c->sizes, c->status, c->redo, 1u);
+            hipLaunchKernelGGL(rcx_enc_static_k, dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)n, block, (u64)1, c->slots, slot, c->sizes,
+                               c->status, static_cast<const u32*>(c->redo));
+        } else {
+            hipLaunchKernelGGL(rcx_enc_static_k, dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)n, block, (u64)1, c->slots, slot,
+                               c->sizes, c->status, static_cast<const u32*>(nullptr));
+        }
         if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
         r = rcx_ctx_sync_status(c, nullptr, nullptr);
         if (r != RCX_OK) return r;
@@ -798,6 +808,22 @@ int rcx_stream_decode(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
         const u64 offs[2] = {0, comp_size};
         HIP_TRY(hipMemcpy(c->h_in, comp, comp_size, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->h_off, offs, sizeof(offs), hipMemcpyHostToDevice));
+        if (count == declared && count >= RCX_MIN_BLOCK && count <= RCX_MAX_BLOCK && decode_lanes(c, 1) != 1) {
+            // the whole stream is wanted and the sink has room: the 4-lane decoder first; it only knows complete, valid
+            // streams, and anything else it reports is redone by the exact one-lane decoder below
+            if ((r = ensure_redo(c, 1)) != RCX_OK) return r;
+            hipLaunchKernelGGL(rcx_dec_static_quad_k<RCX_QUAD_DEC_WAVES>, dim3(1), dim3(64 * RCX_QUAD_DEC_WAVES), 0, nullptr, c->h_in, (u64)comp_size,
+                               c->h_off, (u64)1, block, count, c->h_out, c->status, c->redo, 1u);
+            if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
+            u32 marked = 0;
+            const int fast = rcx_ctx_sync_status(c, nullptr, nullptr); // (clears the latch)
+            HIP_TRY(hipMemcpy(&marked, c->redo, sizeof(u32), hipMemcpyDeviceToHost));
+            if (fast == RCX_OK && marked == 0) {
+                HIP_TRY(hipMemcpy(dst, c->h_out, count, hipMemcpyDeviceToHost));
+                *dst_size = count;
+                return RCX_OK;
+            }
+        }
         hipLaunchKernelGGL(rcx_dec_static_k<true>, dim3(1), dim3(64), 0, nullptr, c->h_in, (u64)comp_size, c->h_off, (u64)1, block, count, c->h_out,
                            c->status, c->status + 2, static_cast<const u32*>(nullptr));
         if (hipGetLastError() != hipSuccess) return RCX_E_HIP;

@@ -92,9 +92,9 @@ def test_shard_blocks():
             assert all(cuts[r][1] == cuts[r + 1][0] for r in range(world - 1))
 
 
-def test_allgatherv_world2_gloo():
+@pytest.mark.parametrize("world", [2, 3])
+def test_allgatherv_gloo(world):
     import torch.multiprocessing as mp
-    world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
@@ -107,4 +107,4 @@ def test_allgatherv_world2_gloo():
         if p.is_alive():
             p.terminate()
             pytest.fail("gloo worker hung")
-    assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
+    assert dict(ret) == {r: "ok" for r in range(world)}, dict(ret)
