@@ -204,13 +204,13 @@ __global__ __launch_bounds__(256) void rcx_enc_rans_k(const u8* __restrict__ src
         const u32 q_ = rcx_div_small_quotient(x, freq_ ? freq_ : 1u, rem_); /* cppans.h:363 */                       \
         x = (ACTIVE) ? (q_ << 12) + rem_ + start_ : x;                                                               \
     }
+        // the byte of round k for this lane; rounds below 0 (the queue runs four rounds ahead) read the block's first byte
+        auto fetch = [&](u32 k) -> u32 { return in[k < rounds ? 8 * k + j : 0u]; };
         u32 r = rounds;
         if (r != 0) { // the block's last round: it may be short
             --r;
             const u32 have = len - 8 * r;
-            const u32 sym = next_byte;
-            next_byte = in[r != 0 ? 8 * (r - 1) + j : j];
-            RCX_RANS8_PUT(live && j < have, sym);
+            RCX_RANS8_PUT(live && j < have, next_byte);
         }
         // whole rounds, as many as every block of the wave still has: no tests for a block that has ended
         u32 common = live ? r : 0xFFFFFFFFu;
@@ -221,17 +221,29 @@ __global__ __launch_bounds__(256) void rcx_enc_rans_k(const u8* __restrict__ src
         }
         if (common == 0xFFFFFFFFu) common = 0;
         if (!live) r = common; // (an octet without a block steps along, reading the start of the buffer; it stores nothing)
-        for (u32 t = 0; t < common; ++t) {
+        // The input bytes come four rounds ahead of their use: a load issued one round ahead (~400 cycles) arrives late.
+        u32 q0 = fetch(r - 1), q1 = fetch(r - 2), q2 = fetch(r - 3), q3 = fetch(r - 4); // q_k = the byte of round r - 1 - k
+        u32 t = 0;
+        for (; t + 4 <= common; t += 4) {
+            RCX_RANS8_PUT(live, q0);
+            q0 = fetch(r - 5);
+            RCX_RANS8_PUT(live, q1);
+            q1 = fetch(r - 6);
+            RCX_RANS8_PUT(live, q2);
+            q2 = fetch(r - 7);
+            RCX_RANS8_PUT(live, q3);
+            q3 = fetch(r - 8);
+            r -= 4;
+        }
+        for (; t < common; ++t) {
+            RCX_RANS8_PUT(live, q0);
+            q0 = q1, q1 = q2, q2 = q3, q3 = fetch(r - 5);
             --r;
-            const u32 sym = next_byte;
-            next_byte = in[r != 0 ? 8 * (r - 1) + j : j]; // the next round's byte is on its way while this one is coded
-            RCX_RANS8_PUT(live, sym);
         }
         while (r != 0) { // blocks longer than the wave's shortest
+            RCX_RANS8_PUT(live, q0);
+            q0 = q1, q1 = q2, q2 = q3, q3 = fetch(r - 5);
             --r;
-            const u32 sym = next_byte;
-            next_byte = in[r != 0 ? 8 * (r - 1) + j : j];
-            RCX_RANS8_PUT(live, sym);
         }
 #undef RCX_RANS8_PUT
     } else {
