@@ -179,25 +179,25 @@ class Context:
         src = _np_u8(data)
         n = len(src)
         nblocks = block_count(n, block)
-        dst = np.zeros(encode_bound(n, block, coder), dtype=np.uint8)
+        dst = np.empty(encode_bound(n, block, coder), dtype=np.uint8)
         offsets = np.zeros(nblocks + 1, dtype=np.uint64)
         size = C.c_uint64()
         st = lib().rcx_encode_blocks(self._h, coder, src.ctypes.data, n, block, dst.ctypes.data, len(dst), C.byref(size),
                                      offsets.ctypes.data)
         _check(st, "rcx_encode_blocks")
-        return dst[: size.value].copy(), offsets
+        return dst[: size.value], offsets
 
     def decode_blocks(self, payload, offsets, block: int, capacity: int | None = None, coder: int = CODER_ADAPTIVE):
         comp = _np_u8(payload)
         offs = np.ascontiguousarray(offsets, dtype=np.uint64)
         nblocks = len(offs) - 1
         cap = nblocks * block if capacity is None else capacity
-        out = np.zeros(max(cap, 1), dtype=np.uint8)
+        out = np.empty(max(cap, 1), dtype=np.uint8)
         size = C.c_uint64()
         st = lib().rcx_decode_blocks(self._h, coder, comp.ctypes.data, len(comp), offs.ctypes.data, nblocks, block,
                                      out.ctypes.data, cap, C.byref(size))
         _check(st, "rcx_decode_blocks")
-        return out[: size.value].copy()
+        return out[: size.value]
 
     # ---- single streams (reference semantics, used by the C++ facade) ------
     def stream_encode(self, data, sink_capacity: int | None = None, coder: int = CODER_ADAPTIVE, dst_cap: int | None = None):
