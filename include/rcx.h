@@ -109,11 +109,11 @@ uint64_t rcx_encode_bound_for(int coder, uint64_t n, uint32_t block);
 
 /*
  * Encode n bytes as independent blocks on the GPU.
- * Replaces, per block: AdaptiveRangeEncoder<T>::initialize + encode (cpprcoder.h:678-720)
- * or RangeEncoder<T>::encode (cpprcoder.h:375-458), and the MemoryStream sink
- * (cpprcoder.h:1031-1054) as the output writer.
+ * Replaces, per block: AdaptiveRangeEncoder<T>::initialize + encode (cpprcoder.h:678-720),
+ * RangeEncoder<T>::encode (cpprcoder.h:375-458) -- and the MemoryStream sink (cpprcoder.h:1031-1054) as the
+ * output writer -- or rANS::encode / encode_simd (cppans.h:497-530, :567-607).
  *   d_src      n input bytes
- *   d_dst      compacted streams, capacity dst_cap (>= rcx_encode_bound(n, block) is always enough)
+ *   d_dst      compacted streams, capacity dst_cap (>= rcx_encode_bound_for(coder, n, block) is always enough)
  *   d_offsets  nblocks+1 u64, exclusive prefix of the per-block stream sizes (written)
  */
 int rcx_encode_blocks_device(rcx_ctx* ctx, int coder, const void* d_src, uint64_t n, uint32_t block,
@@ -121,8 +121,8 @@ int rcx_encode_blocks_device(rcx_ctx* ctx, int coder, const void* d_src, uint64_
 
 /*
  * Decode blocks produced by rcx_encode_blocks_device (or by the reference, block by block).
- * Replaces, per block: AdaptiveRangeDecoder<T>::initialize + decode (cpprcoder.h:859-924)
- * or RangeEncoder<T>::decode (cpprcoder.h:460-519).
+ * Replaces, per block: AdaptiveRangeDecoder<T>::initialize + decode (cpprcoder.h:859-924),
+ * RangeEncoder<T>::decode (cpprcoder.h:460-519) or rANS::decode / decode_simd (cppans.h:532-564, :609-649).
  *   d_comp     the compacted streams, comp_size bytes (a block whose offsets point past comp_size is reported
  *              as RCX_E_CORRUPT and not read)
  *   d_offsets  nblocks+1 u64 as written by the encoder
