@@ -23,6 +23,9 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libcpprcoder_ref.so")
 REF_ANS_SO = os.path.join(ORACLE_DIR, "_ref", "libcppans_ref.so")
+REF_BWT_SO = os.path.join(ORACLE_DIR, "_ref", "libblksort_ref.so")
+
+BWT_BLOCK, BWT_ENCODED = 32768, 32770  # blksort.h:82, :85
 
 CODER_ADAPTIVE, CODER_STATIC, CODER_RANS, CODER_RANS8 = 0, 1, 2, 3
 
@@ -40,8 +43,10 @@ def _u8(a) -> np.ndarray:
 
 
 class Checker:
-    def __init__(self, path: str, prefix: str, kind: str, ans_path: str | None = None):
+    def __init__(self, path: str, prefix: str, kind: str, ans_path: str | None = None, bwt_path: str | None = None):
         self.lib = C.CDLL(path)
+        # block sort (blksort.h): likewise
+        self.bwt = C.CDLL(bwt_path) if bwt_path else (self.lib if prefix == "rco_" else None)
         # rANS (cppans.h): in liboracle.so itself for the restatement, in its own library for the reference build
         self.ans = C.CDLL(ans_path) if ans_path else (self.lib if prefix == "rco_" else None)
         self.prefix = prefix
@@ -79,6 +84,52 @@ class Checker:
             self._rdbr = getattr(A, p + "rans_decode_block_range")
             self._rdbr.restype = C.c_int
             self._rdbr.argtypes = [u8p, C.c_uint64, u32p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, u8p, C.c_int]
+
+        if self.bwt is not None:
+            B = self.bwt
+            for name in ("bwt_encode_bound", "bwt_decode_bound", "bwt_decoded_size"):
+                fn = getattr(B, p + name)
+                fn.restype, fn.argtypes = C.c_uint64, [C.c_uint64]
+            for name in ("bwt_encode", "bwt_decode"):
+                fn = getattr(B, p + name)
+                fn.restype, fn.argtypes = C.c_int, [u8p, C.c_uint64, u8p]
+
+    # ---- block sort (blksort.h) ---------------------------------------------
+    def bwt_encode_bound(self, n: int) -> int:
+        return int(getattr(self.bwt, self.prefix + "bwt_encode_bound")(n))
+
+    def bwt_decode_bound(self, n: int) -> int:
+        return int(getattr(self.bwt, self.prefix + "bwt_decode_bound")(n))
+
+    def bwt_decoded_size(self, n: int) -> int:
+        return int(getattr(self.bwt, self.prefix + "bwt_decoded_size")(n))
+
+    def bwt_encode(self, data, threads: int = 1) -> np.ndarray:
+        """BlkSort::encode: whole 32 KiB blocks -> 32770 bytes each, the rest copied."""
+        src = _u8(data)
+        out = np.zeros(self.bwt_encode_bound(len(src)), dtype=np.uint8)
+        self._bwt_run("bwt_encode", src, out, BWT_BLOCK, BWT_ENCODED, threads)
+        return out
+
+    def bwt_decode(self, enc, threads: int = 1) -> np.ndarray:
+        src = _u8(enc)
+        out = np.zeros(self.bwt_decoded_size(len(src)), dtype=np.uint8)
+        self._bwt_run("bwt_decode", src, out, BWT_ENCODED, BWT_BLOCK, threads)
+        return out
+
+    def _bwt_run(self, name, src, out, unit_in, unit_out, threads):
+        fn = getattr(self.bwt, self.prefix + name)
+        blocks = len(src) // unit_in
+
+        def work(first, last):  # whole blocks [first, last); the last range also takes the copied tail
+            n = (len(src) - first * unit_in) if last == blocks else (last - first) * unit_in
+            if fn(src.ctypes.data + first * unit_in, n, out.ctypes.data + first * unit_out) != 0:
+                raise RuntimeError(f"{self.prefix}{name} failed")
+
+        if blocks == 0:
+            work(0, 0)
+        else:
+            self._fan_out(work, blocks, threads)
 
     # ---- one-shot streams -------------------------------------------------
     @staticmethod
@@ -229,7 +280,7 @@ class Checker:
 
 def build_oracle(force: bool = False) -> None:
     """Compile the C restatement (and the reference build when /root/reference exists)."""
-    sources = [os.path.join(ORACLE_DIR, f) for f in ("rc_oracle.c", "rans_oracle.c")]
+    sources = [os.path.join(ORACLE_DIR, f) for f in ("rc_oracle.c", "rans_oracle.c", "bwt_oracle.c")]
     if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(f) for f in sources):
         subprocess.run(["make", "-C", ORACLE_DIR, "all"], check=True, capture_output=True)
     ref_header = os.environ.get("RCX_REFERENCE", "/root/reference")
@@ -250,7 +301,8 @@ def oracle() -> Checker:
 
 def reference() -> Checker | None:
     if "r" not in _cache:
-        _cache["r"] = (Checker(REF_SO, "ref_", "reference", REF_ANS_SO if os.path.exists(REF_ANS_SO) else None)
+        _cache["r"] = (Checker(REF_SO, "ref_", "reference", REF_ANS_SO if os.path.exists(REF_ANS_SO) else None,
+                               REF_BWT_SO if os.path.exists(REF_BWT_SO) else None)
                        if os.path.exists(REF_SO) else None)
     return _cache["r"]
 
