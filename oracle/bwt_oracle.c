@@ -75,8 +75,12 @@ static void sift(const bwt_sort* s, uint16_t* h /* 1-based */, int32_t i, int32_
     }
     h[i] = x;
 }
+static uint64_t heap_calls; /* test instrumentation: how often the sort fell back to heapsort */
+uint64_t rco_bwt_heap_calls(void) { return heap_calls; }
+
 static void heap(const bwt_sort* s, uint16_t* v, uint32_t size, uint32_t depth)
 {
+    ++heap_calls;
     uint16_t* h = v - 1;
     int32_t n = (int32_t)size;
     for (int32_t k = n >> 1; k >= 1; --k) sift(s, h, k, n, h[k], depth);

@@ -50,6 +50,11 @@ def cases() -> dict[str, np.ndarray]:
     for p, seed, alphabet in ((2, 11, 256), (4, 12, 256), (4, 13, 3), (16, 14, 256), (64, 15, 3), (256, 16, 256),
                               (1024, 17, 4), (4096, 18, 256), (16384, 19, 256), (16384, 20, 2)):
         c[f"period {p} (seed {seed}, {alphabet} symbols)"] = periodic(p, seed, alphabet)
+    # unbalanced partitions: the reference's sort runs out of its 11 levels and falls back to heapsort (blksort.h:284-287)
+    c["period 8192, skewed bytes"] = _tile(np.minimum(mix(8192, 100), 40).astype(np.uint8))
+    c["period 4096, ramp"] = _tile((np.arange(4096) // 16).astype(np.uint8))
+    c["period 2048, sorted"] = _tile(np.sort(mix(2048, 6)))
+    c["skewed bytes"] = np.minimum(mix(BLOCK, 101), 24).astype(np.uint8)   # not periodic, heapsort all the same
     c["three blocks: periodic, random, zeros"] = np.concatenate([periodic(8, 21), mix(BLOCK, 22), np.zeros(BLOCK + 77, np.uint8)])
     return c
 

@@ -38,7 +38,7 @@ def main() -> None:
     out = {"block": bwt_cases.BLOCK, "encoded": bwt_cases.ENCODED, "cases": {}, "canterbury": {}}
     for name, data in bwt_cases.cases().items():
         if name.startswith("period "):
-            p = int(name.split()[1])
+            p = int(name.split()[1].rstrip(","))
             assert bwt_cases.primitive_period(data) == p, name
         enc = ref.bwt_encode(data, threads=8)
         assert len(enc) == ref.bwt_encode_bound(len(data))

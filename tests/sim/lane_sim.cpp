@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../cpprcoder_amd/csrc/rcx_divtab.hpp"
+#include "../../cpprcoder_amd/csrc/rcx_bwt_tie.hpp"
 
 uint64_t rcx_sim_counters[4] = {0, 0, 0, 0};
 
@@ -183,6 +184,18 @@ uint64_t sim_decode_blocks(const uint8_t* comp, const uint64_t* offsets, uint64_
         if (d.taken() > s1 - s0) return b + 1;
     }
     return 0;
+}
+
+// The row index of a periodic 32 KiB block (period p, a power of two), by the replay of the reference's sort that the
+// GPU runs for such blocks (rcx_bwt_tie.hpp).  -> the row, or 0xFFFFFFFF if the part stack overflowed.
+uint32_t sim_bwt_tie_row(const uint8_t* block, uint32_t p)
+{
+    std::vector<uint16_t> rows(32768);
+    for (uint32_t i = 0; i < 32768; ++i) rows[i] = (uint16_t)i;
+    RcxTieSort::Part stack[RCX_TIE_STACK];
+    RcxTieSort t{rows.data(), block, p - 1, 32768u};
+    if (!t.run(stack)) return 0xFFFFFFFFu;
+    return t.row_of_zero();
 }
 
 } // extern "C"

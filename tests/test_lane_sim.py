@@ -19,7 +19,7 @@ SIM_SO = os.path.join(ROOT, "tests", "sim", "liblanesim.so")
 
 @pytest.fixture(scope="module")
 def sim():
-    deps = [SIM_SRC] + [os.path.join(ROOT, "cpprcoder_amd", "csrc", f) for f in ("rcx_lane.hpp", "rcx_divtab.hpp")]
+    deps = [SIM_SRC] + [os.path.join(ROOT, "cpprcoder_amd", "csrc", f) for f in ("rcx_lane.hpp", "rcx_divtab.hpp", "rcx_bwt_tie.hpp")]
     if not os.path.exists(SIM_SO) or any(os.path.getmtime(d) > os.path.getmtime(SIM_SO) for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", SIM_SO, SIM_SRC], check=True)
     L = C.CDLL(SIM_SO)
@@ -157,3 +157,26 @@ def test_long_stream_through_the_halving(sim, oracle):
         comp = np.frombuffer(ref_bytes, np.uint8).copy()
         assert sim.sim_stream_decode_long(comp.ctypes.data, len(comp), n, out.ctypes.data) == 0xFFFFFFFF
         assert np.array_equal(out, data)
+
+
+def test_tie_row_replay_matches_the_reference_rows(sim):
+    """Periodic blocks: the replay of the reference's sort on row classes (rcx_bwt_tie.hpp) lands on the row the real
+    reference stored (tests/golden/bwt.json)."""
+    import json
+
+    import bwt_cases
+    with open(os.path.join(ROOT, "tests", "golden", "bwt.json")) as f:
+        want = json.load(f)["cases"]
+    sim.sim_bwt_tie_row.restype = C.c_uint32
+    sim.sim_bwt_tie_row.argtypes = [C.c_void_p, C.c_uint32]
+    seen = 0
+    for name, data in bwt_cases.cases().items():
+        if len(data) != bwt_cases.BLOCK:
+            continue
+        p = bwt_cases.primitive_period(data)
+        if p == bwt_cases.BLOCK:
+            continue
+        block = np.ascontiguousarray(data)
+        assert sim.sim_bwt_tie_row(block.ctypes.data, p) == want[name]["rows"][0], name
+        seen += 1
+    assert seen >= 10
