@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librcx.so")
 SOURCES = ["rcx_api.hip", "rcx_comm.hip"]
-HEADERS = ["rcx_lane.hpp", "rcx_divtab.hpp", "rcx_kernels.hpp", "rcx_oct.hpp", "rcx_static.hpp", "rcx_rans.hpp", os.path.join("variants", "rcx_variants.hpp"), "rcx_comm.hip", os.path.join("..", "..", "include", "rcx.h")]
+HEADERS = ["rcx_lane.hpp", "rcx_divtab.hpp", "rcx_kernels.hpp", "rcx_oct.hpp", "rcx_static.hpp", "rcx_rans.hpp", "rcx_bwt.hpp", "rcx_bwt_tie.hpp", os.path.join("variants", "rcx_variants.hpp"), "rcx_comm.hip", os.path.join("..", "..", "include", "rcx.h")]
 
 
 def hipcc() -> str:

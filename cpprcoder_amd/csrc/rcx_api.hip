@@ -52,6 +52,9 @@ struct rcx_ctx {
     u64 models_bytes = 0;
     u32* redo = nullptr;        // decode: blocks the quad kernel leaves to the one-lane kernel (corrupt input only)
     u64 redo_count = 0;
+    u32* ties = nullptr;        // block sort: [count, (block, period) ...] of the periodic blocks of the last forward call
+    u64 ties_count = 0;
+    bool bwt_lds_set = false;   // the block-sort kernels have been allowed their dynamic LDS
     DivEntry* divtab = nullptr;
     u32 divtab_block = 0;
     u32* status = nullptr;      // device: [flags, first bad block, track0, track1]
@@ -67,8 +70,8 @@ struct rcx_ctx {
     bool timing = false;
     std::vector<EventPair> pending;
     std::vector<EventPair> pool;
-    double ms[RCX_T_COUNT] = {0, 0, 0, 0};
-    uint64_t launches[RCX_T_COUNT] = {0, 0, 0, 0};
+    double ms[RCX_T_COUNT] = {};
+    uint64_t launches[RCX_T_COUNT] = {};
 };
 
 namespace
@@ -309,6 +312,7 @@ void rcx_ctx_destroy(rcx_ctx* c)
     if (c->starts) (void)hipFree(c->starts);
     if (c->models) (void)hipFree(c->models);
     if (c->redo) (void)hipFree(c->redo);
+    if (c->ties) (void)hipFree(c->ties);
     if (c->divtab) (void)hipFree(c->divtab);
     if (c->status) (void)hipFree(c->status);
     if (c->status_host) (void)hipHostFree(c->status_host);
@@ -1021,6 +1025,137 @@ int rcx_ctx_last_redo(rcx_ctx* c, uint64_t nblocks, uint64_t* count)
     std::vector<u32> host(nblocks);
     HIP_TRY(hipMemcpy(host.data(), c->redo, nblocks * sizeof(u32), hipMemcpyDeviceToHost));
     for (u64 i = 0; i < nblocks; ++i) *count += host[i] != 0;
+    return RCX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Block sort (blksort.h): whole 32 KiB blocks are transformed, what is left over is copied (blksort.h:440-462).
+// ---------------------------------------------------------------------------
+
+uint64_t rcx_bwt_encode_bound(uint64_t n)
+{
+    const u64 blocks = n / RCX_BWT_BLOCK;
+    return blocks * RCX_BWT_ENCODED + (n - blocks * RCX_BWT_BLOCK);
+}
+
+uint64_t rcx_bwt_decode_bound(uint64_t n)
+{
+    const u64 blocks = n / RCX_BWT_BLOCK;
+    return blocks * RCX_BWT_BLOCK + (n - blocks * RCX_BWT_BLOCK);
+}
+
+uint64_t rcx_bwt_decoded_size(uint64_t n)
+{
+    const u64 blocks = n / RCX_BWT_ENCODED;
+    return blocks * RCX_BWT_BLOCK + (n - blocks * RCX_BWT_ENCODED);
+}
+
+int rcx_bwt_reserve(rcx_ctx* c, uint64_t n)
+{
+    if (!c) return RCX_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->bwt_lds_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcx_bwt_fwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCX_BWT_FWD_LDS));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcx_bwt_inv_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCX_BWT_INV_LDS));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcx_bwt_tie_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCX_BWT_TIE_LDS));
+        c->bwt_lds_set = true;
+    }
+    const u64 blocks = n / RCX_BWT_BLOCK;
+    u64 bytes = c->ties_count * sizeof(u32);
+    const int r = grow(reinterpret_cast<void**>(&c->ties), &bytes, (1 + 2 * blocks + 2) * sizeof(u32));
+    c->ties_count = r == RCX_OK ? bytes / sizeof(u32) : 0;
+    return r;
+}
+
+int rcx_bwt_encode_device(rcx_ctx* c, const void* d_src, uint64_t n, void* d_dst, uint64_t dst_cap, void* stream)
+{
+    if (!c || (n && (!d_src || !d_dst))) return RCX_E_ARG;
+    if (dst_cap < rcx_bwt_encode_bound(n)) return RCX_E_CAPACITY;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int r = rcx_bwt_reserve(c, n);
+    if (r != RCX_OK) return r;
+    const u64 blocks = n / RCX_BWT_BLOCK;
+    const u8* src = static_cast<const u8*>(d_src);
+    u8* dst = static_cast<u8*>(d_dst);
+    HIP_TRY(hipMemsetAsync(c->ties, 0, sizeof(u32), s));
+    if (blocks) {
+        Timed t(c, s, RCX_T_BWT_FORWARD);
+        const u32 grid = (u32)(blocks < (1u << 20) ? blocks : (1u << 20));
+        hipLaunchKernelGGL(rcx_bwt_fwd_k, dim3(grid), dim3(RCX_BWT_THREADS), RCX_BWT_FWD_LDS, s, src, blocks, dst, c->ties, c->status);
+        // periodic blocks (rotations that tie) get the row index the reference's sort would leave; usually none
+        const u64 most = 2ull * (u64)c->cus;
+        hipLaunchKernelGGL(rcx_bwt_tie_k, dim3((u32)(blocks < most ? blocks : most)), dim3(64), RCX_BWT_TIE_LDS, s, src, dst,
+                           static_cast<const u32*>(c->ties), c->status);
+    }
+    const u64 rest = n - blocks * RCX_BWT_BLOCK;
+    if (rest) HIP_TRY(hipMemcpyAsync(dst + blocks * RCX_BWT_ENCODED, src + blocks * RCX_BWT_BLOCK, rest, hipMemcpyDeviceToDevice, s));
+    return hipGetLastError() == hipSuccess ? RCX_OK : RCX_E_HIP;
+}
+
+int rcx_bwt_decode_device(rcx_ctx* c, const void* d_src, uint64_t n, void* d_dst, uint64_t dst_cap, void* stream)
+{
+    if (!c || (n && (!d_src || !d_dst))) return RCX_E_ARG;
+    if (dst_cap < rcx_bwt_decoded_size(n)) return RCX_E_CAPACITY;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int r = rcx_bwt_reserve(c, 0);
+    if (r != RCX_OK) return r;
+    const u64 blocks = n / RCX_BWT_ENCODED;
+    const u8* src = static_cast<const u8*>(d_src);
+    u8* dst = static_cast<u8*>(d_dst);
+    if (blocks) {
+        Timed t(c, s, RCX_T_BWT_INVERSE);
+        const u32 grid = (u32)(blocks < (1u << 20) ? blocks : (1u << 20));
+        hipLaunchKernelGGL(rcx_bwt_inv_k, dim3(grid), dim3(RCX_BWT_THREADS), RCX_BWT_INV_LDS, s, src, blocks, dst, c->status);
+    }
+    const u64 rest = n - blocks * RCX_BWT_ENCODED;
+    if (rest) HIP_TRY(hipMemcpyAsync(dst + blocks * RCX_BWT_BLOCK, src + blocks * RCX_BWT_ENCODED, rest, hipMemcpyDeviceToDevice, s));
+    return hipGetLastError() == hipSuccess ? RCX_OK : RCX_E_HIP;
+}
+
+namespace
+{
+int bwt_host(rcx_ctx* c, bool forward, const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t dst_cap, uint64_t* dst_size)
+{
+    if (!c || !dst_size || (n && (!src || !dst))) return RCX_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    const u64 out = forward ? rcx_bwt_encode_bound(n) : rcx_bwt_decoded_size(n);
+    *dst_size = out;
+    if (out > dst_cap) return RCX_E_CAPACITY;
+    if (n == 0) return RCX_OK;
+    int r = grow(reinterpret_cast<void**>(&c->h_in), &c->h_in_bytes, n + 64);
+    if (r != RCX_OK) return r;
+    r = grow(reinterpret_cast<void**>(&c->h_out), &c->h_out_bytes, out + 64);
+    if (r != RCX_OK) return r;
+    HIP_TRY(hipMemcpy(c->h_in, src, n, hipMemcpyHostToDevice));
+    r = forward ? rcx_bwt_encode_device(c, c->h_in, n, c->h_out, out, nullptr) : rcx_bwt_decode_device(c, c->h_in, n, c->h_out, out, nullptr);
+    if (r != RCX_OK) return r;
+    r = rcx_ctx_sync_status(c, nullptr, nullptr);
+    if (r != RCX_OK) return r;
+    HIP_TRY(hipMemcpy(dst, c->h_out, out, hipMemcpyDeviceToHost));
+    return RCX_OK;
+}
+} // namespace
+
+int rcx_bwt_encode(rcx_ctx* c, const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t dst_cap, uint64_t* dst_size)
+{
+    return bwt_host(c, true, src, n, dst, dst_cap, dst_size);
+}
+
+int rcx_bwt_decode(rcx_ctx* c, const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t dst_cap, uint64_t* dst_size)
+{
+    return bwt_host(c, false, src, n, dst, dst_cap, dst_size);
+}
+
+int rcx_bwt_last_ties(rcx_ctx* c, uint64_t* count)
+{
+    if (!c || !count) return RCX_E_ARG;
+    *count = 0;
+    if (!c->ties) return RCX_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    u32 v = 0;
+    HIP_TRY(hipMemcpy(&v, c->ties, sizeof(u32), hipMemcpyDeviceToHost));
+    *count = v;
     return RCX_OK;
 }
 

@@ -1,0 +1,419 @@
+// rcx_bwt.hpp -- the reference's block sort (blksort.h) on gfx950: the Burrows-Wheeler transform of 32 KiB blocks
+// that its harness puts in front of the entropy coders (test/main.cpp:961-986), and the inverse.
+//
+//   rcx_bwt_fwd_k   one workgroup of 16 waves per block: the 32768 rotations are sorted by prefix doubling inside
+//                   the CU's LDS, the last column and the row of rotation 0 leave as blksort.h:511-518 writes them
+//   rcx_bwt_tie_k   periodic blocks only (rotations that tie): one lane replays the reference's unstable sort on
+//                   row classes for the row index it would store (rcx_bwt_tie.hpp)
+//   rcx_bwt_inv_k   one workgroup per block: stable counting sort of the column (blksort.h:365-397), then the
+//                   walk of blksort.h:663-667 cut into 1024 pieces that are walked at once
+//
+// What is sorted and how.  SA[k] = the rotation in row k, RK[i] = the first row of the group rotation i is in.  Start:
+// rows ordered by two bytes (two stable 8-bit counting passes).  Round h = 2, 4, ...: the rows are in h-order, so the
+// sequence SA[k] - h (k = 0, 1, ...) lists the rotations by their SECOND h bytes; sorted stably by RK[.] -- the group
+// of their FIRST h bytes, a 15-bit key, two 8-bit passes -- it is the 2h-order (Manber-Myers).  Then the groups are
+// split where neighbours differ in (RK[i], RK[i + h]).  All indices are mod 32768: these are rotations, not suffixes.
+// It ends when every row is alone in its group -- or when a round splits nothing, which happens exactly when the
+// block is periodic (if h bytes and 2h bytes give the same classes, so does any depth): the number of groups then is
+// the period, the column is right whatever the order inside the ties, and the row index is rcx_bwt_tie_k's.
+//
+// A stable counting pass of 32768 keys by 1024 lanes: wave w owns keys [2048 w, 2048 w + 2048), 64 at a time in index
+// order; within the 64, lanes with the same digit find each other with 8 ballots, the lowest ones first; per wave and
+// digit a running count in LDS gives the rank among the wave's earlier keys; after an exclusive scan of the 16 x 256
+// counts in (digit, wave) order every key knows its place.  The keys stay in registers between the count and the
+// scatter, so one array is sorted in place.
+//
+// LDS (forward): SA 64 KiB | RK 64 KiB | counts 8 KiB | 256 B.  RK's space first holds the block itself (the two-byte
+// keys are bytes of it) and at the end again (the column is gathered from it); SA's space ends as the staging buffer
+// the 32770 output bytes leave from in aligned 16-byte pieces.  One workgroup per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rcx_bwt_tie.hpp"
+#include "rcx_lane.hpp"
+
+#define RCX_BWT_BLOCK 32768u   /* blksort.h:82 */
+#define RCX_BWT_MASK 32767u
+#define RCX_BWT_ENCODED 32770u /* blksort.h:85 */
+#define RCX_BWT_THREADS 1024u
+#define RCX_BWT_WAVES 16u
+
+#define RCX_BWT_FWD_SA 0u
+#define RCX_BWT_FWD_RK 65536u
+#define RCX_BWT_FWD_CNT 131072u
+#define RCX_BWT_FWD_MISC (131072u + 8192u)
+#define RCX_BWT_FWD_LDS (RCX_BWT_FWD_MISC + 256u)
+
+#define RCX_BWT_INV_NEXT 0u
+#define RCX_BWT_INV_ENC 65536u                 /* 32770 bytes + up to 15 of alignment */
+#define RCX_BWT_INV_OUT (65536u + 32832u)      /* 32768 bytes + up to 15 */
+#define RCX_BWT_INV_CNT (RCX_BWT_INV_OUT + 32800u)
+#define RCX_BWT_INV_JUMP (RCX_BWT_INV_CNT + 8192u) /* u16[1024] */
+#define RCX_BWT_INV_ACC (RCX_BWT_INV_JUMP + 2048u) /* u32[1024] */
+#define RCX_BWT_INV_MISC (RCX_BWT_INV_ACC + 4096u)
+#define RCX_BWT_INV_LDS (RCX_BWT_INV_MISC + 256u)
+
+#define RCX_BWT_TIE_ROWS 0u
+#define RCX_BWT_TIE_WORD 65536u
+#define RCX_BWT_TIE_STACK (65536u + 16384u)
+#define RCX_BWT_TIE_LDS (RCX_BWT_TIE_STACK + RCX_TIE_STACK * 16u + 64u)
+
+// ---------------------------------------------------------------------------
+// global <-> LDS copies of one block.  The LDS image starts at lds + (address & 15), so that both sides of the 16-byte
+// pieces in the middle are aligned whatever the caller's pointer is; a few threads move the ragged ends bytewise.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ u32 rcx_bwt_stage_in(u8* lds, const u8* g, u32 bytes)
+{
+    const u32 tid = threadIdx.x;
+    const u32 shift = (u32)(reinterpret_cast<uintptr_t>(g) & 15u);
+    const u32 head = (16u - shift) & 15u;
+    const u32 pieces = (bytes - head) >> 4, tail = (bytes - head) & 15u;
+    if (tid < head) lds[shift + tid] = g[tid];
+    for (u32 i = tid; i < pieces; i += RCX_BWT_THREADS)
+        *reinterpret_cast<U4*>(lds + shift + head + 16u * i) = *reinterpret_cast<const U4*>(g + head + 16u * i);
+    if (tid < tail) lds[shift + head + 16u * pieces + tid] = g[head + 16u * pieces + tid];
+    return shift;
+}
+// the image must have been built at lds + (g & 15)
+__device__ __forceinline__ void rcx_bwt_stage_out(u8* g, const u8* lds, u32 bytes)
+{
+    const u32 tid = threadIdx.x;
+    const u32 shift = (u32)(reinterpret_cast<uintptr_t>(g) & 15u);
+    const u32 head = (16u - shift) & 15u;
+    const u32 pieces = (bytes - head) >> 4, tail = (bytes - head) & 15u;
+    if (tid < head) g[tid] = lds[shift + tid];
+    for (u32 i = tid; i < pieces; i += RCX_BWT_THREADS)
+        *reinterpret_cast<U4*>(g + head + 16u * i) = *reinterpret_cast<const U4*>(lds + shift + head + 16u * i);
+    if (tid < tail) g[head + 16u * pieces + tid] = lds[shift + head + 16u * pieces + tid];
+}
+
+// lanes of the wave holding the same 8-bit digit as this one
+__device__ __forceinline__ u64 rcx_bwt_match8(u32 d)
+{
+    u64 peers = ~0ull;
+#pragma unroll
+    for (u32 b = 0; b < 8; ++b) {
+        const bool bit = ((d >> b) & 1u) != 0;
+        const u64 bal = __builtin_amdgcn_ballot_w64(bit);
+        peers &= bit ? bal : ~bal;
+    }
+    return peers;
+}
+
+// exclusive prefix sum over the workgroup (all 1024 threads call it); misc: 16 dwords
+__device__ __forceinline__ u32 rcx_bwt_block_excl(u32 v, u32* misc)
+{
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    u32 incl = v;
+#pragma unroll
+    for (u32 o = 1; o < 64; o <<= 1) {
+        const u32 t = (u32)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) misc[w] = incl;
+    __syncthreads();
+    u32 base = 0;
+#pragma unroll
+    for (u32 i = 0; i < RCX_BWT_WAVES; ++i) {
+        const u32 t = misc[i];
+        base += i < w ? t : 0u;
+    }
+    __syncthreads();
+    return base + incl - v;
+}
+
+// One stable counting pass: arr[place(k)] = element(k) for k = 0..32767, ordered by digit(k), equal digits in the
+// order of k.  KEYS(k, e, d) yields element and digit; it may read arr (every read is done before the first write).
+template <class Keys>
+__device__ __forceinline__ void rcx_bwt_pass(uint16_t* arr, uint16_t* cnt, u32* misc, Keys keys)
+{
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    uint16_t* mine = cnt + 256u * w;
+    // (u16 stores: a dword store through another pointer type may legally be moved behind the u16 reads below)
+    mine[lane] = 0;
+    mine[lane + 64] = 0;
+    mine[lane + 128] = 0;
+    mine[lane + 192] = 0;
+    const u64 below_me = (1ull << lane) - 1ull;
+    u32 held[32]; // element | rank among the wave's earlier keys with the same digit << 16
+    u32 digits[8];
+#pragma unroll
+    for (u32 q = 0; q < 8; ++q) digits[q] = 0;
+#pragma unroll
+    for (u32 it = 0; it < 32; ++it) {
+        const u32 k = 2048u * w + 64u * it + lane;
+        u32 e, d;
+        keys(k, e, d);
+        const u64 peers = rcx_bwt_match8(d);
+        const u32 below = (u32)__popcll(peers & below_me), total = (u32)__popcll(peers);
+        const u32 old = mine[d];
+        if (below + 1 == total) mine[d] = (uint16_t)(old + total); // the highest of the peers
+        held[it] = e | ((old + below) << 16);
+        digits[it >> 2] |= d << (8u * (it & 3u));
+    }
+    __syncthreads();
+    { // 4096 counts -> their exclusive prefix in (digit, wave) order
+        const u32 d = tid >> 2, w0 = 4u * (tid & 3u);
+        const u32 v0 = cnt[256u * (w0 + 0) + d], v1 = cnt[256u * (w0 + 1) + d], v2 = cnt[256u * (w0 + 2) + d], v3 = cnt[256u * (w0 + 3) + d];
+        const u32 base = rcx_bwt_block_excl(v0 + v1 + v2 + v3, misc);
+        cnt[256u * (w0 + 0) + d] = (uint16_t)base;
+        cnt[256u * (w0 + 1) + d] = (uint16_t)(base + v0);
+        cnt[256u * (w0 + 2) + d] = (uint16_t)(base + v0 + v1);
+        cnt[256u * (w0 + 3) + d] = (uint16_t)(base + v0 + v1 + v2);
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 it = 0; it < 32; ++it) {
+        const u32 d = (digits[it >> 2] >> (8u * (it & 3u))) & 0xFFu;
+        arr[(u32)mine[d] + (held[it] >> 16)] = (uint16_t)held[it];
+    }
+    __syncthreads();
+}
+
+// New groups: row k starts one if KEY(SA[k]) differs from KEY(SA[k - 1]); RK[SA[k]] = the first row of k's group.
+// Thread t looks at rows [32 t, 32 t + 32).  Returns the number of groups.  misc: 32 dwords.
+template <class Key>
+__device__ __forceinline__ u32 rcx_bwt_rerank(const uint16_t* sa, uint16_t* rk, u32* misc, Key key)
+{
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, k0 = 32u * tid;
+    u32 s[32];
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+        const U4 v = reinterpret_cast<const U4*>(sa + k0)[q];
+        s[8 * q + 0] = v.x & 0xFFFFu;
+        s[8 * q + 1] = v.x >> 16;
+        s[8 * q + 2] = v.y & 0xFFFFu;
+        s[8 * q + 3] = v.y >> 16;
+        s[8 * q + 4] = v.z & 0xFFFFu;
+        s[8 * q + 5] = v.z >> 16;
+        s[8 * q + 6] = v.w & 0xFFFFu;
+        s[8 * q + 7] = v.w >> 16;
+    }
+    u32 prev = key((u32)sa[(k0 + RCX_BWT_MASK) & RCX_BWT_MASK]);
+    u32 bits = 0;
+#pragma unroll
+    for (u32 i = 0; i < 32; ++i) {
+        const u32 kk = key(s[i]);
+        bits |= (kk != prev ? 1u : 0u) << i;
+        prev = kk;
+    }
+    if (tid == 0) bits |= 1u;
+    // the last group start at or before each row: inside the thread from `bits`, before it a running maximum
+    const u32 last = bits ? k0 + 31u - (u32)__clz(bits) : 0u;
+    u32 run = last, sum = (u32)__popc(bits);
+#pragma unroll
+    for (u32 o = 1; o < 64; o <<= 1) {
+        const u32 t = (u32)__shfl_up((int)run, o, 64);
+        if (lane >= o) run = run > t ? run : t;
+    }
+#pragma unroll
+    for (u32 o = 32; o > 0; o >>= 1) sum += (u32)__shfl_xor((int)sum, o, 64);
+    const u32 before = (u32)__shfl_up((int)run, 1, 64);
+    if (lane == 63) misc[w] = run;
+    if (lane == 0) misc[16 + w] = sum;
+    __syncthreads(); // (every key has been read: RK may be rewritten)
+    u32 carry = lane ? before : 0u, groups = 0;
+#pragma unroll
+    for (u32 i = 0; i < RCX_BWT_WAVES; ++i) {
+        const u32 m = misc[i];
+        if (i < w) carry = carry > m ? carry : m;
+        groups += misc[16 + i];
+    }
+#pragma unroll
+    for (u32 i = 0; i < 32; ++i) {
+        const u32 m = bits & ((2u << i) - 1u);
+        rk[s[i]] = (uint16_t)(m ? k0 + 31u - (u32)__clz(m) : carry);
+    }
+    __syncthreads();
+    return groups;
+}
+
+// ties: [0] = count, then (block, period) pairs of the periodic blocks with a period above 1
+__global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src, u64 nblocks, u8* __restrict__ dst, u32* __restrict__ ties, u32* status)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 rcx_bwt_lds[];
+    u8* lds = rcx_bwt_lds;
+    uint16_t* sa = reinterpret_cast<uint16_t*>(lds + RCX_BWT_FWD_SA);
+    uint16_t* rk = reinterpret_cast<uint16_t*>(lds + RCX_BWT_FWD_RK);
+    uint16_t* cnt = reinterpret_cast<uint16_t*>(lds + RCX_BWT_FWD_CNT);
+    u32* misc = reinterpret_cast<u32*>(lds + RCX_BWT_FWD_MISC);
+    const u32 tid = threadIdx.x;
+    for (u64 b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const u8* in = src + b * RCX_BWT_BLOCK;
+        u8* out = dst + b * RCX_BWT_ENCODED;
+        u8* text = lds + RCX_BWT_FWD_RK;
+        const u32 shift = rcx_bwt_stage_in(text, in, RCX_BWT_BLOCK);
+        __syncthreads();
+        // rows by their first two bytes: the second byte first (identity order in), then the first
+#pragma nounroll
+        for (u32 first = 0; first < 2; ++first)
+            rcx_bwt_pass(sa, cnt, misc, [&](u32 k, u32& e, u32& d) {
+                e = first ? (u32)sa[k] : k;
+                d = text[shift + ((e + 1u - first) & RCX_BWT_MASK)];
+            });
+        u32 groups = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return ((u32)text[shift + s] << 8) | text[shift + ((s + 1u) & RCX_BWT_MASK)]; });
+        for (u32 h = 2; groups < RCX_BWT_BLOCK && h < RCX_BWT_BLOCK; h <<= 1) {
+#pragma nounroll
+            for (u32 high = 0; high < 2; ++high)
+                rcx_bwt_pass(sa, cnt, misc, [&](u32 k, u32& e, u32& d) {
+                    e = ((u32)sa[k] - (high ? 0u : h)) & RCX_BWT_MASK;
+                    d = ((u32)rk[e] >> (8u * high)) & 0xFFu;
+                });
+            const u32 now = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return ((u32)rk[s] << 16) | rk[(s + h) & RCX_BWT_MASK]; });
+            if (now == groups) break; // nothing split: the block is periodic, `groups` is its period
+            groups = now;
+        }
+        // the last column (blksort.h:511-518): byte in front of every row's rotation
+        u32 s[32];
+        {
+            const u32 k0 = 32u * tid;
+#pragma unroll
+            for (u32 q = 0; q < 4; ++q) {
+                const U4 v = reinterpret_cast<const U4*>(sa + k0)[q];
+                s[8 * q + 0] = v.x & 0xFFFFu;
+                s[8 * q + 1] = v.x >> 16;
+                s[8 * q + 2] = v.y & 0xFFFFu;
+                s[8 * q + 3] = v.y >> 16;
+                s[8 * q + 4] = v.z & 0xFFFFu;
+                s[8 * q + 5] = v.z >> 16;
+                s[8 * q + 6] = v.w & 0xFFFFu;
+                s[8 * q + 7] = v.w >> 16;
+            }
+#pragma unroll
+            for (u32 i = 0; i < 32; ++i)
+                if (s[i] == 0) misc[32] = k0 + i;
+        }
+        __syncthreads(); // SA is in registers, RK is done with
+        (void)rcx_bwt_stage_in(text, in, RCX_BWT_BLOCK);
+        __syncthreads();
+        u8* stage = lds + RCX_BWT_FWD_SA;
+        const u32 oshift = (u32)(reinterpret_cast<uintptr_t>(out) & 15u);
+#pragma unroll
+        for (u32 i = 0; i < 32; ++i) stage[oshift + 32u * tid + i] = text[shift + ((s[i] + RCX_BWT_MASK) & RCX_BWT_MASK)];
+        if (tid == 0) {
+            // all rotations equal: the reference's sort moves nothing and row 0 stays where it is (rcx_bwt_tie.hpp)
+            const u32 row = groups == 1 ? 0u : misc[32];
+            stage[oshift + RCX_BWT_BLOCK] = (u8)(row & 0xFFu); // a uint16_t copied on a little-endian host (blksort.h:518)
+            stage[oshift + RCX_BWT_BLOCK + 1] = (u8)(row >> 8);
+            if (groups > 1 && groups < RCX_BWT_BLOCK) {
+                if (groups & (groups - 1u)) {
+                    rcx_flag(status, RCX_ST_CORRUPT, b); // a period divides 32768: anything else is a bug here, not data
+                } else {
+                    const u32 at = atomicAdd(&ties[0], 1u);
+                    ties[1 + 2 * at] = (u32)b;
+                    ties[2 + 2 * at] = groups;
+                }
+            }
+        }
+        __syncthreads();
+        rcx_bwt_stage_out(out, stage, RCX_BWT_ENCODED);
+        __syncthreads();
+    }
+}
+
+// Periodic blocks: the row index as the reference's sort leaves it.  One wave per listed block, lane 0 replays.
+__global__ __launch_bounds__(64) void rcx_bwt_tie_k(const u8* __restrict__ src, u8* __restrict__ dst, const u32* __restrict__ ties, u32* status)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 rcx_bwt_lds[];
+    uint16_t* rows = reinterpret_cast<uint16_t*>(rcx_bwt_lds + RCX_BWT_TIE_ROWS);
+    u8* word = rcx_bwt_lds + RCX_BWT_TIE_WORD;
+    RcxTieSort::Part* stack = reinterpret_cast<RcxTieSort::Part*>(rcx_bwt_lds + RCX_BWT_TIE_STACK);
+    const u32 lane = threadIdx.x;
+    const u32 count = ties[0];
+    for (u32 i = blockIdx.x; i < count; i += gridDim.x) {
+        const u64 b = ties[1 + 2 * i];
+        const u32 p = ties[2 + 2 * i];
+        const u8* in = src + b * RCX_BWT_BLOCK;
+        for (u32 r = lane; r < RCX_BWT_BLOCK; r += 64) rows[r] = (uint16_t)r;
+        for (u32 r = lane; r < p; r += 64) word[r] = in[r];
+        __syncthreads();
+        RcxTieSort t{rows, word, p - 1u, RCX_BWT_BLOCK};
+        if (lane == 0 && !t.run(stack)) rcx_flag(status, RCX_ST_CORRUPT, b); // (cannot happen: the stack bound)
+        __syncthreads();
+        for (u32 r = lane; r < RCX_BWT_BLOCK; r += 64)
+            if (rows[r] == 0) {
+                u8* out = dst + b * RCX_BWT_ENCODED + RCX_BWT_BLOCK;
+                out[0] = (u8)(r & 0xFFu);
+                out[1] = (u8)(r >> 8);
+            }
+        __syncthreads();
+    }
+}
+
+// The inverse (blksort.h:543-679).  next[r] = where the r-th smallest byte of the column sits (equal bytes in their
+// order): the stable counting pass above with the column byte as the digit.  The reference then walks
+// p = next[top]; out[i] = column[p]; p = next[p] for 32768 steps.  Here the rows congruent to next[top] mod 32 are
+// 1024 starting points; every thread walks from its start to the next start it meets (about 32 steps, all threads at
+// once), the pieces are put in order by pointer jumping over the 1024 (start -> start it ran into) links, and a
+// second walk writes the bytes where they belong.  `next` is a permutation whatever the input, so every walk ends;
+// if the walk from next[top] closes after C < 32768 steps (a periodic block, or garbage) the reference keeps going
+// round, and so do the writes here (position + m C).
+__global__ __launch_bounds__(1024) void rcx_bwt_inv_k(const u8* __restrict__ src, u64 nblocks, u8* __restrict__ dst, u32* status)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 rcx_bwt_lds[];
+    u8* lds = rcx_bwt_lds;
+    uint16_t* next = reinterpret_cast<uint16_t*>(lds + RCX_BWT_INV_NEXT);
+    uint16_t* cnt = reinterpret_cast<uint16_t*>(lds + RCX_BWT_INV_CNT);
+    uint16_t* jump = reinterpret_cast<uint16_t*>(lds + RCX_BWT_INV_JUMP);
+    u32* acc = reinterpret_cast<u32*>(lds + RCX_BWT_INV_ACC);
+    u32* misc = reinterpret_cast<u32*>(lds + RCX_BWT_INV_MISC);
+    const u32 tid = threadIdx.x;
+    for (u64 b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const u8* in = src + b * RCX_BWT_ENCODED;
+        u8* out = dst + b * RCX_BWT_BLOCK;
+        u8* enc = lds + RCX_BWT_INV_ENC;
+        const u32 shift = rcx_bwt_stage_in(enc, in, RCX_BWT_ENCODED);
+        __syncthreads();
+        const u8* col = enc + shift;
+        rcx_bwt_pass(next, cnt, misc, [&](u32 k, u32& e, u32& d) {
+            e = k;
+            d = col[k];
+        });
+        u32 top = (u32)col[RCX_BWT_BLOCK] | ((u32)col[RCX_BWT_BLOCK + 1] << 8);
+        if (top >= RCX_BWT_BLOCK) { // the reference would read outside its arrays (blksort.h:663)
+            if (tid == 0) rcx_flag(status, RCX_ST_CORRUPT, b);
+            top &= RCX_BWT_MASK;
+        }
+        const u32 x0 = next[top];
+        const u32 residue = x0 & 31u, first = x0 >> 5;
+        const u32 start = residue + 32u * tid;
+        u32 steps = 0, r = start;
+        do {
+            r = next[r];
+            ++steps;
+        } while ((r & 31u) != residue && steps < RCX_BWT_BLOCK); // (a permutation comes back to its start: the bound never cuts in)
+        const u32 into = r >> 5;
+        // distance from every piece to the first one along the links (the first piece is made a sink)
+        jump[tid] = (uint16_t)(tid == first ? first : into);
+        acc[tid] = tid == first ? 0u : steps;
+        __syncthreads();
+#pragma nounroll
+        for (u32 round = 0; round < 10; ++round) {
+            const u32 j = jump[tid];
+            const u32 a = acc[tid] + acc[j];
+            const u32 jj = jump[j];
+            __syncthreads();
+            jump[tid] = (uint16_t)jj;
+            acc[tid] = a;
+            __syncthreads();
+        }
+        if (tid == first) misc[0] = steps + (into == first ? 0u : acc[into]); // the length of the whole walk's cycle
+        __syncthreads();
+        const u32 cycle = misc[0];
+        const bool on_walk = tid == first || jump[tid] == first;
+        u8* stage = lds + RCX_BWT_INV_OUT;
+        const u32 oshift = (u32)(reinterpret_cast<uintptr_t>(out) & 15u);
+        if (on_walk) {
+            const u32 at = tid == first ? 0u : cycle - acc[tid];
+            r = start;
+            for (u32 i = 0; i < steps; ++i) {
+                const u8 c = col[r];
+                for (u32 p = at + i; p < RCX_BWT_BLOCK; p += cycle) stage[oshift + p] = c;
+                r = next[r];
+            }
+        }
+        __syncthreads();
+        rcx_bwt_stage_out(out, stage, RCX_BWT_BLOCK);
+        __syncthreads();
+    }
+}

@@ -393,3 +393,4 @@ __global__ __launch_bounds__(64) void rcx_dec_resume_k(RcxDState* __restrict__ s
 #include "variants/rcx_variants.hpp"
 #include "rcx_static.hpp"
 #include "rcx_rans.hpp"
+#include "rcx_bwt.hpp"

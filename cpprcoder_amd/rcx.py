@@ -17,7 +17,8 @@ LIB_PATH = os.environ.get("RCX_LIBRARY") or os.path.join(HERE, "librcx.so")  # R
 OK, PENDING, ERROR, E_ARG, E_CAPACITY, E_CORRUPT, E_HIP, E_NOMEM, E_COMM = 0, 1, -1, -2, -3, -4, -5, -6, -7
 COMM_ID_BYTES = 128
 CODER_ADAPTIVE, CODER_STATIC, CODER_RANS, CODER_RANS8 = 0, 1, 2, 3
-T_ENCODE, T_SCAN, T_SCATTER, T_DECODE, T_COUNT = 0, 1, 2, 3, 4
+T_ENCODE, T_SCAN, T_SCATTER, T_DECODE, T_BWT_FORWARD, T_BWT_INVERSE, T_COUNT = 0, 1, 2, 3, 4, 5, 6
+BWT_BLOCK, BWT_ENCODED = 32768, 32770  # blksort.h:82, :85
 MIN_BLOCK, MAX_BLOCK, MAX_STREAM = 16, (1 << 24) - 256, 0x7FFFFFFF
 
 # every symbol include/rcx.h declares (tests check that the library exports all of them)
@@ -30,6 +31,8 @@ EXPORTS = (
     "rcx_dstream_create", "rcx_dstream_destroy", "rcx_dstream_decode",
     "rcx_comm_unique_id", "rcx_comm_create", "rcx_comm_destroy", "rcx_comm_rank", "rcx_comm_size", "rcx_exchange_plan",
     "rcx_allgatherv_segments",
+    "rcx_bwt_encode_bound", "rcx_bwt_decode_bound", "rcx_bwt_decoded_size", "rcx_bwt_reserve", "rcx_bwt_encode_device",
+    "rcx_bwt_decode_device", "rcx_bwt_encode", "rcx_bwt_decode", "rcx_bwt_last_ties",
 )
 
 
@@ -89,6 +92,14 @@ def lib() -> C.CDLL:
         L.rcx_exchange_plan.restype, L.rcx_exchange_plan.argtypes = i32, [vp, vp, i32, vp, vp]
         L.rcx_allgatherv_segments.restype = i32
         L.rcx_allgatherv_segments.argtypes = [vp, vp, vp, u64, vp, u64, vp, u64, vp, vp, vp]
+        for name in ("rcx_bwt_encode_bound", "rcx_bwt_decode_bound", "rcx_bwt_decoded_size"):
+            getattr(L, name).restype, getattr(L, name).argtypes = u64, [u64]
+        L.rcx_bwt_reserve.restype, L.rcx_bwt_reserve.argtypes = i32, [vp, u64]
+        for name in ("rcx_bwt_encode_device", "rcx_bwt_decode_device"):
+            getattr(L, name).restype, getattr(L, name).argtypes = i32, [vp, vp, u64, vp, u64, vp]
+        for name in ("rcx_bwt_encode", "rcx_bwt_decode"):
+            getattr(L, name).restype, getattr(L, name).argtypes = i32, [vp, vp, u64, vp, u64, C.POINTER(u64)]
+        L.rcx_bwt_last_ties.restype, L.rcx_bwt_last_ties.argtypes = i32, [vp, C.POINTER(u64)]
         _lib = L
     return _lib
 
@@ -107,6 +118,14 @@ def block_bound(block: int, coder: int = CODER_ADAPTIVE) -> int:
 
 def encode_bound(n: int, block: int, coder: int = CODER_ADAPTIVE) -> int:
     return int(lib().rcx_encode_bound_for(coder, n, block))
+
+
+def bwt_encode_bound(n: int) -> int:
+    return int(lib().rcx_bwt_encode_bound(n))
+
+
+def bwt_decoded_size(n: int) -> int:
+    return int(lib().rcx_bwt_decoded_size(n))
 
 
 def _check(status: int, where: str) -> None:
@@ -199,6 +218,39 @@ class Context:
         _check(st, "rcx_decode_blocks")
         return out[: size.value]
 
+    # ---- block sort (blksort.h) ----------------------------------------------
+    def bwt_encode(self, data) -> np.ndarray:
+        """BlkSort::encode on a host buffer -> the encoded bytes."""
+        src = _np_u8(data)
+        dst = np.full(bwt_encode_bound(len(src)) + 64, 0xA5, dtype=np.uint8)
+        size = C.c_uint64()
+        _check(lib().rcx_bwt_encode(self._h, src.ctypes.data, len(src), dst.ctypes.data, len(dst) - 64, C.byref(size)), "rcx_bwt_encode")
+        assert bool((dst[size.value:] == 0xA5).all()), "rcx_bwt_encode wrote past its size"
+        return dst[: size.value]
+
+    def bwt_decode(self, enc) -> np.ndarray:
+        src = _np_u8(enc)
+        dst = np.full(bwt_decoded_size(len(src)) + 64, 0xA5, dtype=np.uint8)
+        size = C.c_uint64()
+        _check(lib().rcx_bwt_decode(self._h, src.ctypes.data, len(src), dst.ctypes.data, len(dst) - 64, C.byref(size)), "rcx_bwt_decode")
+        assert bool((dst[size.value:] == 0xA5).all()), "rcx_bwt_decode wrote past its size"
+        return dst[: size.value]
+
+    def bwt_encode_device(self, src, dst, stream=None) -> None:
+        """src, dst: uint8 cuda tensors (dst >= bwt_encode_bound(src.numel())); enqueues only."""
+        _check(lib().rcx_bwt_encode_device(self._h, src.data_ptr(), src.numel(), dst.data_ptr(), dst.numel(), self._stream_handle(stream)),
+               "rcx_bwt_encode_device")
+
+    def bwt_decode_device(self, src, n: int, dst, stream=None) -> None:
+        """src: uint8 cuda tensor holding n encoded bytes; dst >= bwt_decoded_size(n)."""
+        _check(lib().rcx_bwt_decode_device(self._h, src.data_ptr(), n, dst.data_ptr(), dst.numel(), self._stream_handle(stream)),
+               "rcx_bwt_decode_device")
+
+    def bwt_last_ties(self) -> int:
+        count = C.c_uint64(0)
+        _check(lib().rcx_bwt_last_ties(self._h, C.byref(count)), "rcx_bwt_last_ties")
+        return int(count.value)
+
     # ---- single streams (reference semantics, used by the C++ facade) ------
     def stream_encode(self, data, sink_capacity: int | None = None, coder: int = CODER_ADAPTIVE, dst_cap: int | None = None):
         """-> (status, request_size, stream bytes).  dst_cap: size of the buffer handed to the library (default: exactly
@@ -239,7 +291,7 @@ class Context:
         ms = (C.c_double * T_COUNT)()
         launches = (C.c_uint64 * T_COUNT)()
         _check(lib().rcx_ctx_get_timing(self._h, ms, launches, int(reset)), "rcx_ctx_get_timing")
-        names = ("encode", "scan", "scatter", "decode")
+        names = ("encode", "scan", "scatter", "decode", "bwt_forward", "bwt_inverse")
         return {names[i]: {"ms": ms[i], "launches": int(launches[i])} for i in range(T_COUNT)}
 
 

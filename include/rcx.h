@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define RCX_VERSION 200 /* 0.2.0 */
+#define RCX_VERSION 210 /* 0.2.1 */
 
 /* Status codes.  0 / 1 / -1 are the reference's Status enum (cpprcoder.h:112-117). */
 enum {
@@ -182,6 +182,38 @@ int rcx_dstream_decode(rcx_dstream* stream, const uint8_t* bytes, uint64_t size,
                        uint64_t* produced_now, uint32_t* request_size);
 
 /*
+ * The block sort (blksort.h): the Burrows-Wheeler transform of 32 KiB blocks the reference harness runs in front of
+ * its entropy coders (test/main.cpp:961-986), and its inverse.  Replaces blksort::BlkSort:
+ *   rcx_bwt_encode_bound   BlkSort::encodeBound (blksort.h:426-431): n + 2 bytes per whole block of 32768
+ *   rcx_bwt_decode_bound   BlkSort::decodeBound (blksort.h:433-438): a bound, and as the reference computes it, n
+ *   rcx_bwt_decoded_size   what BlkSort::decode writes for n encoded bytes (blksort.h:451-462: n / 32770 blocks of
+ *                          32768 bytes and the rest as it is)
+ *   rcx_bwt_encode(_device)   BlkSort::encode (blksort.h:440-449): every whole block becomes the last column of its
+ *       sorted rotations + the row of the unrotated block as a little-endian u16; a shorter rest is copied.  Byte for
+ *       byte the reference's output -- including the row it stores for a PERIODIC block, whose rotations tie: that row
+ *       depends on the moves of the reference's unstable sort, which are replayed for such blocks.
+ *   rcx_bwt_decode(_device)   BlkSort::decode (blksort.h:451-462, the source is not modified).  A stored row of 32768 or
+ *       more, with which the reference reads outside its arrays, is RCX_E_CORRUPT (through rcx_ctx_sync_status for
+ *       the device call).
+ * The _device calls take device pointers of any alignment, enqueue on `stream` and do not synchronise; scratch is
+ * grown on first use or ahead of time by rcx_bwt_reserve(ctx, n).  Capacities are checked before anything is enqueued
+ * (RCX_E_CAPACITY); the host-buffer calls also report the size needed in *dst_size.
+ * rcx_bwt_last_ties: how many blocks of the last forward call were periodic with a period above 1 and went through the
+ * replay (diagnostic; synchronises).
+ */
+#define RCX_BWT_BLOCK_BYTES 32768u
+#define RCX_BWT_ENCODED_BYTES 32770u
+uint64_t rcx_bwt_encode_bound(uint64_t n);
+uint64_t rcx_bwt_decode_bound(uint64_t n);
+uint64_t rcx_bwt_decoded_size(uint64_t n);
+int rcx_bwt_reserve(rcx_ctx* ctx, uint64_t n);
+int rcx_bwt_encode_device(rcx_ctx* ctx, const void* d_src, uint64_t n, void* d_dst, uint64_t dst_cap, void* stream);
+int rcx_bwt_decode_device(rcx_ctx* ctx, const void* d_src, uint64_t n, void* d_dst, uint64_t dst_cap, void* stream);
+int rcx_bwt_encode(rcx_ctx* ctx, const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t dst_cap, uint64_t* dst_size);
+int rcx_bwt_decode(rcx_ctx* ctx, const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t dst_cap, uint64_t* dst_size);
+int rcx_bwt_last_ties(rcx_ctx* ctx, uint64_t* count);
+
+/*
  * Multi-GPU (new; the reference has no multi-device code).  Blocks are independent, so n bytes are sharded over the
  * GPUs of a node as contiguous block ranges and coded with the calls above, no collective involved.  The one real
  * exchange of the path is putting the compressed segments of all GPUs -- and their block tables -- together on
@@ -211,7 +243,7 @@ int rcx_allgatherv_segments(rcx_comm* comm, const void* d_segment, const uint64_
 
 /* Per-kernel device time of the calls made since the last reset, in milliseconds,
  * measured with HIP events on the stream the kernels ran on (off by default). */
-enum { RCX_T_ENCODE = 0, RCX_T_SCAN = 1, RCX_T_SCATTER = 2, RCX_T_DECODE = 3, RCX_T_COUNT = 4 };
+enum { RCX_T_ENCODE = 0, RCX_T_SCAN = 1, RCX_T_SCATTER = 2, RCX_T_DECODE = 3, RCX_T_BWT_FORWARD = 4, RCX_T_BWT_INVERSE = 5, RCX_T_COUNT = 6 };
 /* How many of the first `nblocks` blocks of the LAST rcx_encode_blocks* / rcx_decode_blocks* call on this
  * context were handed to the one-lane kernels (the many-lane kernels mark, and do not finish, a block whose
  * carry runs through more output bytes than they keep in LDS, or whose stream asks for a symbol past the
