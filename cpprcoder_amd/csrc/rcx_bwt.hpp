@@ -87,17 +87,22 @@ __device__ __forceinline__ void rcx_bwt_stage_out(u8* g, const u8* lds, u32 byte
     if (tid < tail) g[head + 16u * pieces + tid] = lds[shift + head + 16u * pieces + tid];
 }
 
-// lanes of the wave holding the same 8-bit digit as this one
-__device__ __forceinline__ u64 rcx_bwt_match8(u32 d)
+// Lanes of the wave holding the same 8-bit digit as this one: how many of them are below this lane, and how many
+// there are.  Per bit: the lanes that have it set (one compare = one ballot), and every lane keeps those that agree
+// with it (xnor with its own bit spread over the word).
+__device__ __forceinline__ void rcx_bwt_match8(u32 d, u32& below, u32& total)
 {
-    u64 peers = ~0ull;
+    u32 lo = ~0u, hi = ~0u;
 #pragma unroll
     for (u32 b = 0; b < 8; ++b) {
-        const bool bit = ((d >> b) & 1u) != 0;
-        const u64 bal = __builtin_amdgcn_ballot_w64(bit);
-        peers &= bit ? bal : ~bal;
+        const u32 mine = (u32)((s32)(d << (31u - b)) >> 31); // bit b of d on every bit
+        u64 bal;
+        asm("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(bal) : "v"(mine)); // (as a ballot the compiler tests a second, shifted copy of d)
+        lo &= ~((u32)bal ^ mine);
+        hi &= ~((u32)(bal >> 32) ^ mine);
     }
-    return peers;
+    below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+    total = (u32)__popc(lo) + (u32)__popc(hi);
 }
 
 // exclusive prefix sum over the workgroup (all 1024 threads call it); misc: 16 dwords
@@ -122,10 +127,11 @@ __device__ __forceinline__ u32 rcx_bwt_block_excl(u32 v, u32* misc)
     return base + incl - v;
 }
 
-// One stable counting pass: arr[place(k)] = element(k) for k = 0..32767, ordered by digit(k), equal digits in the
-// order of k.  KEYS(k, e, d) yields element and digit; it may read arr (every read is done before the first write).
-template <class Keys>
-__device__ __forceinline__ void rcx_bwt_pass(uint16_t* arr, uint16_t* cnt, u32* misc, Keys keys)
+// One stable counting pass over arr[0..32767]: the elements end up ordered by their digit, equal digits in the order
+// they were in.  ELEM(x) turns what is read from arr into the element that is stored back, DIGIT(e) is its digit.
+// Both run on whole batches of 32 per lane before anything is counted, so their LDS reads overlap.
+template <class Elem, class Digit>
+__device__ __forceinline__ void rcx_bwt_pass(uint16_t* arr, uint16_t* cnt, u32* misc, Elem elem, Digit digit)
 {
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     uint16_t* mine = cnt + 256u * w;
@@ -134,22 +140,28 @@ __device__ __forceinline__ void rcx_bwt_pass(uint16_t* arr, uint16_t* cnt, u32* 
     mine[lane + 64] = 0;
     mine[lane + 128] = 0;
     mine[lane + 192] = 0;
-    const u64 below_me = (1ull << lane) - 1ull;
     u32 held[32]; // element | rank among the wave's earlier keys with the same digit << 16
     u32 digits[8];
+    const uint16_t* in = arr + 2048u * w + lane;
 #pragma unroll
-    for (u32 q = 0; q < 8; ++q) digits[q] = 0;
+    for (u32 it = 0; it < 32; ++it) held[it] = in[64u * it];
+#pragma unroll
+    for (u32 it = 0; it < 32; ++it) held[it] = elem(held[it]);
+    {
+        u32 dg[32];
+#pragma unroll
+        for (u32 it = 0; it < 32; ++it) dg[it] = digit(held[it]);
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) digits[q] = dg[4 * q] | (dg[4 * q + 1] << 8) | (dg[4 * q + 2] << 16) | (dg[4 * q + 3] << 24);
+    }
 #pragma unroll
     for (u32 it = 0; it < 32; ++it) {
-        const u32 k = 2048u * w + 64u * it + lane;
-        u32 e, d;
-        keys(k, e, d);
-        const u64 peers = rcx_bwt_match8(d);
-        const u32 below = (u32)__popcll(peers & below_me), total = (u32)__popcll(peers);
+        const u32 d = (digits[it >> 2] >> (8u * (it & 3u))) & 0xFFu;
+        u32 below, total;
+        rcx_bwt_match8(d, below, total);
         const u32 old = mine[d];
         if (below + 1 == total) mine[d] = (uint16_t)(old + total); // the highest of the peers
-        held[it] = e | ((old + below) << 16);
-        digits[it >> 2] |= d << (8u * (it & 3u));
+        held[it] |= (old + below) << 16;
     }
     __syncthreads();
     { // 4096 counts -> their exclusive prefix in (digit, wave) order
@@ -163,9 +175,13 @@ __device__ __forceinline__ void rcx_bwt_pass(uint16_t* arr, uint16_t* cnt, u32* 
     }
     __syncthreads();
 #pragma unroll
-    for (u32 it = 0; it < 32; ++it) {
-        const u32 d = (digits[it >> 2] >> (8u * (it & 3u))) & 0xFFu;
-        arr[(u32)mine[d] + (held[it] >> 16)] = (uint16_t)held[it];
+    for (u32 q = 0; q < 8; ++q) asm volatile("" : "+v"(digits[q])); // (addresses are formed again here, not kept from above)
+    {
+        u32 base[32];
+#pragma unroll
+        for (u32 it = 0; it < 32; ++it) base[it] = mine[(digits[it >> 2] >> (8u * (it & 3u))) & 0xFFu];
+#pragma unroll
+        for (u32 it = 0; it < 32; ++it) arr[base[it] + (held[it] >> 16)] = (uint16_t)held[it];
     }
     __syncthreads();
 }
@@ -244,21 +260,20 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
         u8* text = lds + RCX_BWT_FWD_RK;
         const u32 shift = rcx_bwt_stage_in(text, in, RCX_BWT_BLOCK);
         __syncthreads();
-        // rows by their first two bytes: the second byte first (identity order in), then the first
+        // rows by their first two bytes: the second byte first (rows in index order), then the first
+#pragma unroll
+        for (u32 i = 0; i < 32; ++i) sa[32u * tid + i] = (uint16_t)(32u * tid + i);
+        __syncthreads();
 #pragma nounroll
-        for (u32 first = 0; first < 2; ++first)
-            rcx_bwt_pass(sa, cnt, misc, [&](u32 k, u32& e, u32& d) {
-                e = first ? (u32)sa[k] : k;
-                d = text[shift + ((e + 1u - first) & RCX_BWT_MASK)];
-            });
+        for (u32 second = 1; second < 2; --second)
+            rcx_bwt_pass(sa, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)text[shift + ((e + second) & RCX_BWT_MASK)]; });
         u32 groups = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return ((u32)text[shift + s] << 8) | text[shift + ((s + 1u) & RCX_BWT_MASK)]; });
         for (u32 h = 2; groups < RCX_BWT_BLOCK && h < RCX_BWT_BLOCK; h <<= 1) {
 #pragma nounroll
-            for (u32 high = 0; high < 2; ++high)
-                rcx_bwt_pass(sa, cnt, misc, [&](u32 k, u32& e, u32& d) {
-                    e = ((u32)sa[k] - (high ? 0u : h)) & RCX_BWT_MASK;
-                    d = ((u32)rk[e] >> (8u * high)) & 0xFFu;
-                });
+            for (u32 high = 0; high < 2; ++high) {
+                const u32 back = high ? 0u : h, down = 8u * high;
+                rcx_bwt_pass(sa, cnt, misc, [&](u32 x) { return (x - back) & RCX_BWT_MASK; }, [&](u32 e) { return ((u32)rk[e] >> down) & 0xFFu; });
+            }
             const u32 now = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return ((u32)rk[s] << 16) | rk[(s + h) & RCX_BWT_MASK]; });
             if (now == groups) break; // nothing split: the block is periodic, `groups` is its period
             groups = now;
@@ -365,10 +380,10 @@ __global__ __launch_bounds__(1024) void rcx_bwt_inv_k(const u8* __restrict__ src
         const u32 shift = rcx_bwt_stage_in(enc, in, RCX_BWT_ENCODED);
         __syncthreads();
         const u8* col = enc + shift;
-        rcx_bwt_pass(next, cnt, misc, [&](u32 k, u32& e, u32& d) {
-            e = k;
-            d = col[k];
-        });
+#pragma unroll
+        for (u32 i = 0; i < 32; ++i) next[32u * tid + i] = (uint16_t)(32u * tid + i);
+        __syncthreads();
+        rcx_bwt_pass(next, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)col[e]; });
         u32 top = (u32)col[RCX_BWT_BLOCK] | ((u32)col[RCX_BWT_BLOCK + 1] << 8);
         if (top >= RCX_BWT_BLOCK) { // the reference would read outside its arrays (blksort.h:663)
             if (tid == 0) rcx_flag(status, RCX_ST_CORRUPT, b);
