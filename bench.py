@@ -66,28 +66,39 @@ def baseline_config(name: str, n: int, block: int, world: int) -> str:
     return "none of BASELINE.json's configs (a variation for diagnosis)"
 
 
-def cpu_baseline(data: np.ndarray, block: int, coder: int = 0):
-    """The reference's CPU coder on a bounded sample of the same bytes the GPU coded, all host cores."""
+def cpu_baseline(data: np.ndarray, block: int, coder: int = 0, blksort: bool = False):
+    """The reference's CPU coder on a bounded sample of the same bytes the GPU coded, all host cores.  With blksort the
+    reference's block sort runs in front of it and behind it (BlkSort::encode / decode, as test/main.cpp:961-986)."""
     import oracle_lib
     oracle_lib.build_oracle()
     chk = oracle_lib.reference() or oracle_lib.oracle()
+    if blksort and chk.bwt is None:
+        chk = oracle_lib.oracle()
     cores = os.cpu_count() or 1
     t0 = time.time()
-    slots, sizes = chk.encode_blocks(data, block, coder=coder, threads=cores)
+    coded = chk.bwt_encode(data, threads=cores) if blksort else data
+    slots, sizes = chk.encode_blocks(coded, block, coder=coder, threads=cores)
     t1 = time.time()
-    back, ok = chk.decode_blocks(slots, sizes, block, len(data), coder=coder, threads=cores)
+    back, ok = chk.decode_blocks(slots, sizes, block, len(coded), coder=coder, threads=cores)
+    if blksort:
+        back = chk.bwt_decode(back, threads=cores)
     t2 = time.time()
     assert ok and np.array_equal(back, data)
-    one = data[: min(len(data), 8 << 20)]
+    one = data[: min(len(data), (2 << 20) if blksort else (8 << 20))]
     s0 = time.time()
-    s_slots, s_sizes = chk.encode_blocks(one, block, coder=coder, threads=1)
+    one_coded = chk.bwt_encode(one) if blksort else one
+    s_slots, s_sizes = chk.encode_blocks(one_coded, block, coder=coder, threads=1)
     s1 = time.time()
-    chk.decode_blocks(s_slots, s_sizes, block, len(one), coder=coder, threads=1)
+    one_back, _ = chk.decode_blocks(s_slots, s_sizes, block, len(one_coded), coder=coder, threads=1)
+    if blksort:
+        chk.bwt_decode(one_back)
     s2 = time.time()
     mb = len(data) / 1e6
     return {
         "value": round(mb / (t2 - t0), 2), "unit": "MB/s", "cores": cores, "kind": chk.kind,
-        "sample": f"the first {len(data) >> 20} MiB of the very bytes the GPU coded, {block >> 10} KiB blocks, encode+decode round trip, "
+        "sample": f"the first {len(data) >> 20} MiB of the very bytes the GPU coded, "
+                  + ("block sort of 32 KiB blocks (blksort.h) in front of and behind the coder, " if blksort else "")
+                  + f"{block >> 10} KiB blocks, encode+decode round trip, "
                   f"{cores} threads over a block range split (fresh coder per block, as test/main.cpp:325-344)",
         "encode_MBps": round(mb / (t1 - t0), 2), "decode_MBps": round(mb / (t2 - t1), 2),
         "one_thread_encode_MBps": round(len(one) / 1e6 / (s1 - s0), 2), "one_thread_decode_MBps": round(len(one) / 1e6 / (s2 - s1), 2),
@@ -120,6 +131,9 @@ def main() -> None:
     ap.add_argument("--block", type=int, default=BLOCK)
     ap.add_argument("--coder", default="adaptive", choices=["adaptive", "static", "rans", "rans8"],
                     help="adaptive (BASELINE.json's metric) | static | rans | rans8: the same protocol on the sibling coders (diagnosis; not the headline)")
+    ap.add_argument("--blksort", action="store_true",
+                    help="the reference's block sort (blksort.h, 32 KiB blocks) in front of the encoder and behind the decoder, as its "
+                         "harness does in front of zlib / zstd (test/main.cpp:961-986): a pipeline for diagnosis, not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=256)
     ap.add_argument("--exchange", action="store_true",
@@ -152,12 +166,15 @@ def main() -> None:
         args.workload = "uniform" if world == 1 else "zipf"
     n, block = args.bytes, args.block
     coder = ("adaptive", "static", "rans", "rans8").index(args.coder)
-    nblocks = rcx.block_count(n, block)
+    m = rcx.bwt_encode_bound(n) if args.blksort else n  # what the coder is handed (blksort.h:426-431)
+    nblocks = rcx.block_count(m, block)
     seed = 12345 + rank  # mt19937(12345 + rank) per shard
     src, host_src, gen_s = make_workload(args.workload, n, seed, device)
     ctx = rcx.Context(local)
-    ctx.reserve(n, block, coder)
-    bound = rcx.encode_bound(n, block, coder)
+    ctx.reserve(m, block, coder)
+    bound = rcx.encode_bound(m, block, coder)
+    sorted_buf = torch.empty(m, dtype=torch.uint8, device=device) if args.blksort else None
+    decoded_buf = torch.empty(m, dtype=torch.uint8, device=device) if args.blksort else None
     # Two compressed buffers: with the exchange on, step i+1 encodes into the other one while the exchange of
     # step i is still reading this one (the exchange of a step overlaps its own decode AND the next step's encode).
     nbuf = 2 if exchange else 1
@@ -180,11 +197,15 @@ def main() -> None:
         comp, offs = comps[b], offss[b]
         if released[b] is not None:
             main_stream.wait_event(released[b])
-        ctx.encode_blocks_device(src, block, comp, offs, coder=coder)
+        if args.blksort:
+            ctx.bwt_encode_device(src, sorted_buf)
+        ctx.encode_blocks_device(sorted_buf if args.blksort else src, block, comp, offs, coder=coder)
         if exchange:
             side.wait_stream(main_stream)  # the exchange starts when the encode is done (and queues behind the previous one)
         # the decoder takes the block table from HBM: no host round trip between encode and decode
-        ctx.decode_blocks_device(comp, bound, offs, n, block, out, coder=coder)
+        ctx.decode_blocks_device(comp, bound, offs, m, block, decoded_buf if args.blksort else out, coder=coder)
+        if args.blksort:
+            ctx.bwt_decode_device(decoded_buf, m, out)
         if exchange:
             # one call: sizes all-gather (its one host sync waits for the encode only), then every segment and table
             # part point to point straight into place -- while the decode above runs on the main stream
@@ -256,6 +277,11 @@ def main() -> None:
             dec_name = {1: "rcx_dec_static_quad_k", 2: "rcx_dec_rans1_quad_k", 3: "rcx_dec_rans8_k"}[coder]
         dom, dom_ms = (dec_name, dec_ms) if dec_ms >= enc_ms else (enc_name, enc_ms)
         algo_bytes = (1.0 + ratio) * n  # 1 read + r write per input byte (or r read + 1 write)
+        fwd_ms = timing["bwt_forward"]["ms"] / max(1, timing["bwt_forward"]["launches"])
+        inv_ms = timing["bwt_inverse"]["ms"] / max(1, timing["bwt_inverse"]["launches"])
+        if args.blksort and max(fwd_ms, inv_ms) > dom_ms:  # the transform reads a block and writes it (+ 2 bytes)
+            dom, dom_ms = ("rcx_bwt_fwd_k", fwd_ms) if fwd_ms >= inv_ms else ("rcx_bwt_inv_k", inv_ms)
+            algo_bytes = float(n + m)
         achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
         # HBM bytes per launch of the dominant kernel from the PMC passes (separate rocprofv3 --pmc runs cannot happen
         # inside this process): replayed from profiles/pmc_traffic.json, and only if that file was recorded on the
@@ -281,16 +307,18 @@ def main() -> None:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{n >> 20} MiB synthetic {args.workload} bytes per GPU ({workload_origin}), "
                                    f"{block >> 10} KiB blocks, encode+decode round trip resident in HBM",
-                       "baseline_config": baseline_config(args.workload, n, block, world) if coder == 0 else
+                       "baseline_config": "none of BASELINE.json's configs: the reference's block sort (blksort.h) in front of the coder" if args.blksort else
+                                          baseline_config(args.workload, n, block, world) if coder == 0 else
                                           f"none of BASELINE.json's configs: the {args.coder} coder (cppans.h / RangeEncoder) on that shape",
-                       "coder": args.coder,
+                       "coder": args.coder, "blksort": bool(args.blksort),
                        "bytes_per_gpu": n, "block": block, "blocks_per_gpu": nblocks,
                        "parallelism": f"blocks sharded over {world} GPU(s), one process per GPU"
                                       + ("; rcx_allgatherv_segments (RCCL send/recv straight into place) overlapped with the decode and with the next step's encode" if exchange else "")},
             "roundtrip_ok": roundtrip_ok, "ratio": round(ratio, 6),
             "encode_MBps": round(n / 1e6 / ((enc_ms + scan_ms + scat_ms) * 1e-3), 1),
             "decode_MBps": round(n / 1e6 / (dec_ms * 1e-3), 1),
-            "kernel_ms": {"encode": round(enc_ms, 4), "scan": round(scan_ms, 4), "scatter": round(scat_ms, 4), "decode": round(dec_ms, 4)},
+            "kernel_ms": dict({"encode": round(enc_ms, 4), "scan": round(scan_ms, 4), "scatter": round(scat_ms, 4), "decode": round(dec_ms, 4)},
+                              **({"bwt_forward": round(fwd_ms, 4), "bwt_inverse": round(inv_ms, 4)} if args.blksort else {})),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": int(algo_bytes),
@@ -309,12 +337,16 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             try:
                 sample = host_src[: min(n, args.cpu_sample_mib << 20) // block * block or n]
-                cb, cpu_sizes = cpu_baseline(sample, block, coder)
+                if args.blksort:  # the transform costs the CPU ~ 5 ms a block: a smaller sample (whole 32 KiB blocks)
+                    sample = sample[: min(len(sample), 64 << 20)]
+                cb, cpu_sizes = cpu_baseline(sample, block, coder, args.blksort)
                 line["cpu_baseline"] = cb
                 line["gpu_over_cpu"] = round(line["value"] / cb["value"], 1)
-                # same bytes on both sides: the GPU's per-block stream sizes must be the CPU coder's
-                gpu_sizes = (offs[1: len(cpu_sizes) + 1] - offs[: len(cpu_sizes)]).cpu().numpy()
-                line["cpu_baseline"]["block_sizes_equal_gpu"] = bool(np.array_equal(gpu_sizes, cpu_sizes.astype(np.int64)))
+                # same bytes on both sides: the GPU's per-block stream sizes must be the CPU coder's (with the block
+                # sort in front the sample's last coder block is cut differently: all but that one)
+                k = len(cpu_sizes) - (1 if args.blksort else 0)
+                gpu_sizes = (offs[1: k + 1] - offs[:k]).cpu().numpy()
+                line["cpu_baseline"]["block_sizes_equal_gpu"] = bool(np.array_equal(gpu_sizes, cpu_sizes[:k].astype(np.int64)))
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         os.write(_REAL_STDOUT, (json.dumps(line) + "\n").encode())

@@ -1,7 +1,8 @@
 """python -m cpprcoder_amd c|d|t ...  -- compress / decompress / test files with the MI355X block coder.
 
-    python -m cpprcoder_amd c [-b BLOCK] [--static | --coder adaptive|static|rans|rans8] IN OUT
-                                                               IN -> RCXB container (cpprcoder_amd/container.py)
+    python -m cpprcoder_amd c [-b BLOCK] [--blksort] [--static | --coder adaptive|static|rans|rans8] IN OUT
+                                                               IN -> RCXB container (cpprcoder_amd/container.py);
+                                                               --blksort: the reference's block sort (blksort.h) first
     python -m cpprcoder_amd d IN OUT                           container -> original bytes
     python -m cpprcoder_amd t FILE...                          the reference harness's row per file
                                                                (|file|ratio|encode|decode|, test/main.cpp:346-356):
@@ -22,6 +23,7 @@ def main(argv=None) -> int:
     c.add_argument("-b", "--block", type=int, default=65536)
     c.add_argument("--static", action="store_true")
     c.add_argument("--coder", choices=CODERS, default=None)
+    c.add_argument("--blksort", action="store_true")
     c.add_argument("src")
     c.add_argument("dst")
     d = sub.add_parser("d")
@@ -31,6 +33,7 @@ def main(argv=None) -> int:
     t.add_argument("-b", "--block", type=int, default=65536)
     t.add_argument("--static", action="store_true")
     t.add_argument("--coder", choices=CODERS, default=None)
+    t.add_argument("--blksort", action="store_true")
     t.add_argument("files", nargs="+")
     a = ap.parse_args(argv)
     from . import container, rcx
@@ -39,7 +42,7 @@ def main(argv=None) -> int:
     try:
         if a.cmd == "c":
             data = open(a.src, "rb").read()
-            blob = container.pack(data, a.block, coder, ctx)
+            blob = container.pack(data, a.block, coder, ctx, blksort=a.blksort)
             open(a.dst, "wb").write(blob)
             print(f"{a.src}: {len(data)} -> {len(blob)} bytes ({len(blob) / max(len(data), 1):.6f})")
         elif a.cmd == "d":
@@ -53,7 +56,7 @@ def main(argv=None) -> int:
             for path in a.files:
                 data = open(path, "rb").read()
                 t0 = time.perf_counter()
-                blob = container.pack(data, a.block, coder, ctx)
+                blob = container.pack(data, a.block, coder, ctx, blksort=a.blksort)
                 t1 = time.perf_counter()
                 back = container.unpack(blob, ctx)
                 t2 = time.perf_counter()

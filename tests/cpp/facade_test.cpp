@@ -8,6 +8,7 @@
 //   facade_test senc|sdec <in> <out> <sink_capacity>       static RangeEncoder<>::encode / decode
 //   facade_test blocks <in> <out> <block>                  BlockCoder round trip; out = compacted streams
 //   facade_test renc|rdec <in> <out> <size> <simd>         cppans::rANS::encode(_simd) / decode(_simd), test/main.cpp:384-387
+//   facade_test benc|bdec <in> <out> 0                     blksort::BlkSort::encode / decode, test/main.cpp:812-825
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,6 +16,7 @@
 #include <iterator>
 #include <vector>
 
+#include "cpprcoder_amd/blksort.h"
 #include "cpprcoder_amd/cppans.h"
 #include "cpprcoder_amd/cpprcoder.h"
 
@@ -108,6 +110,19 @@ int main(int argc, char** argv)
                              : cppans::rANS::decode(static_cast<u32>(dst.size()), dst.data(), static_cast<u32>(in.size()), in.data());
         dump(argv[3], dst.data(), dst.size());
         printf("%u %zu\n", ret, dst.size());
+        return 0;
+    }
+    if (!strcmp(argv[1], "benc") || !strcmp(argv[1], "bdec")) { // run_blksort: test/main.cpp:812-825
+        const bool forward = !strcmp(argv[1], "benc");
+        const uint32_t size = static_cast<uint32_t>(in.size());
+        // decode writes blocks * 32768 + rest bytes, blocks = size / 32770 (blksort.h:451-462)
+        const uint32_t room = forward ? blksort::BlkSort::encodeBound(size) : static_cast<uint32_t>(rcx_bwt_decoded_size(size));
+        std::vector<u8> dst(room);
+        blksort::BlkSort blk;
+        if (forward) blk.encode(size, dst.data(), in.data());
+        else blk.decode(size, dst.data(), in.data());
+        dump(argv[3], dst.data(), dst.size());
+        printf("%d %u %u\n", blk.ok() ? 1 : 0, room, blksort::BlkSort::decodeBound(size));
         return 0;
     }
     if (!strcmp(argv[1], "blocks")) {

@@ -32,6 +32,18 @@ def test_header_round_trip_and_rejections():
         container.parse(bytes(bad))
     empty = container.parse(container.header_bytes(1, 65536, 0, np.zeros(1, np.uint64)))
     assert empty["nblocks"] == 0 and len(empty["payload"]) == 0
+    # block-sorted first (flags bit 0): the coder saw 2 bytes more per whole 32 KiB (blksort.h:426-431)
+    n = 3 * 32768 - 2
+    assert container.coded_size(n, container.FLAG_BLKSORT) == n + 4
+    offs = np.array([0, 10, 20, 30, 40], np.uint64)                   # 98306 bytes in blocks of 32768: 4 blocks, not 3
+    c = container.parse(container.header_bytes(0, 32768, n, offs, container.FLAG_BLKSORT) + bytes(40))
+    assert c["flags"] == container.FLAG_BLKSORT and c["nblocks"] == 4
+    with pytest.raises(container.ContainerError):
+        container.header_bytes(0, 32768, n, offs)                     # without the flag the same table is wrong
+    bad = bytearray(container.header_bytes(0, 4096, 100, np.array([0, 5], np.uint64)) + bytes(5))
+    bad[6] = 2                                                         # an unknown flag
+    with pytest.raises(container.ContainerError):
+        container.parse(bytes(bad))
 
 
 @pytest.mark.gpu
@@ -52,6 +64,20 @@ def test_pack_unpack_and_blocks_are_the_references(oracle):
                         got = c["payload"][int(c["offsets"][b]): int(c["offsets"][b + 1])]
                         assert np.array_equal(got, slots[b, : int(sizes[b])]), (coder, n, block, b)
                 assert container.unpack(blob, ctx) == data.tobytes()
+        # block sort in front of the coder: the coder's input is BlkSort::encode's output
+        data = workloads.canterbury_concat()[:1_000_000]
+        plain = container.pack(data, 65536, 0, ctx)
+        blob = container.pack(data, 65536, 0, ctx, blksort=True)
+        c = container.parse(blob)
+        assert c["flags"] == container.FLAG_BLKSORT and c["n"] == len(data)
+        sorted_first = oracle.bwt_encode(data, threads=8)
+        slots, sizes = oracle.encode_blocks(sorted_first, 65536, threads=4)
+        assert np.array_equal(np.diff(c["offsets"].astype(np.int64)), sizes.astype(np.int64))
+        assert container.unpack(blob, ctx) == data.tobytes()
+        # The transform permutes each block's bytes: an order-0 model sees the same counts, so the size barely moves
+        # (the reference pairs its block sort with zlib / zstd, test/main.cpp:961-970, and its own move-to-front stage
+        # is compiled out, blksort.h:54).
+        assert abs(len(blob) - len(plain)) < 0.01 * len(plain)
     finally:
         ctx.close()
 
@@ -73,3 +99,7 @@ def test_cli_round_trip(tmp_path):
     r = run("t", "--coder", "rans8", "-b", "16384", str(src))
     assert r.returncode == 0 and "MISMATCH" not in r.stdout, r.stdout + r.stderr
     assert (tmp_path / "out.rcxb").stat().st_size < 0.6 * src.stat().st_size
+    r = run("c", "--blksort", str(src), str(tmp_path / "sorted.rcxb"))
+    assert r.returncode == 0, r.stderr
+    r = run("d", str(tmp_path / "sorted.rcxb"), str(tmp_path / "back2.bin"))
+    assert r.returncode == 0 and (tmp_path / "back2.bin").read_bytes() == src.read_bytes()

@@ -125,3 +125,21 @@ def test_facade_rans(exe, tmp_path, oracle):
             small = 1100 if not simd else 1130
             (size, cap), out = run(exe, tmp_path, "renc", v, small, simd)  # a stream that does not fit: 0 (cppans.h:522, :599)
             assert size == (len(ref) if len(ref) <= small else 0)
+
+
+def test_facade_blksort(exe, tmp_path, oracle):
+    """blksort::BlkSort::encode / decode (blksort.h:440-462) through include/cpprcoder_amd/blksort.h, as run_blksort
+    calls them (test/main.cpp:812-825)."""
+    import bwt_cases
+    files = workloads.canterbury_files()
+    for v in (files["alice29.txt"], b"short", workloads.zipf(3 * 32768, 9).tobytes(), bwt_cases.periodic(64, 15, 3).tobytes()):
+        ref = oracle.bwt_encode(v)
+        (ok, room, bound), out = run(exe, tmp_path, "benc", v, 0)
+        assert ok == 1 and room == len(ref) == len(v) + 2 * (len(v) // 32768) and bound == len(v)
+        assert out == ref.tobytes()
+        (ok, room, _), back = run(exe, tmp_path, "bdec", ref, 0)
+        assert ok == 1 and back == bytes(v)
+    bad = oracle.bwt_encode(files["alice29.txt"]).copy()
+    bad[32769] |= 0x80  # row index past the block
+    (ok, _, _), _ = run(exe, tmp_path, "bdec", bad, 0)
+    assert ok == 0

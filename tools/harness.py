@@ -52,6 +52,25 @@ def main():
         t2 = time.perf_counter()
         ok = np.array_equal(back, data)
         print(f"|{name}|{len(data)}|{len(payload)}|{len(payload) / len(data):.6f}|{(t1 - t0) * 1e6:.0f}|{(t2 - t1) * 1e6:.0f}|{'ok' if ok else 'MISMATCH'}|")
+    print()
+    # test/main.cpp:790-840 (run_blksort): BlkSort::encode + decode of the whole file; "ratio" there is size / encoded size
+    print("BLKSORT (rcx_bwt_encode / rcx_bwt_decode, host buffers incl. PCIe copies), and the block-sorted file through the")
+    print("adaptive coder in 64 KiB blocks next to the plain file (container --blksort)")
+    print("|file|bytes|encoded|encode us|decode us|round trip|adaptive 64 KiB plain|after block sort|")
+    print("|:---|---:|---:|---:|---:|:---|---:|---:|")
+    ctx.bwt_encode(np.zeros(65536, np.uint8))
+    for name in workloads.CANTERBURY_ORDER:
+        data = np.frombuffer(files[name], np.uint8)
+        t0 = time.perf_counter()
+        enc = ctx.bwt_encode(data)
+        t1 = time.perf_counter()
+        back = ctx.bwt_decode(enc)
+        t2 = time.perf_counter()
+        ok = np.array_equal(back, data)
+        plain, _ = ctx.encode_blocks(data, 65536)
+        sorted_first, _ = ctx.encode_blocks(enc, 65536)
+        print(f"|{name}|{len(data)}|{len(enc)}|{(t1 - t0) * 1e6:.0f}|{(t2 - t1) * 1e6:.0f}|{'ok' if ok else 'MISMATCH'}|"
+              f"{len(plain) / len(data):.6f}|{len(sorted_first) / len(data):.6f}|")
     ctx.close()
 
 
