@@ -17,13 +17,18 @@
 // block is periodic (if h bytes and 2h bytes give the same classes, so does any depth): the number of groups then is
 // the period, the column is right whatever the order inside the ties, and the row index is rcx_bwt_tie_k's.
 //
+// Rounds get cheaper: a rotation that is alone in its group has its final row (RK carries a flag for it), and once the
+// rotations that are not fit a list in LDS (11264 entries; text gets there after two or three rounds) a round only
+// touches those: the SA[k] - h that are still open are collected in row order, that list is sorted by group with the
+// same two counting passes -- a third or a tenth as long -- and lands in the open rows, which it fills exactly.
+//
 // A stable counting pass of 32768 keys by 1024 lanes: wave w owns keys [2048 w, 2048 w + 2048), 64 at a time in index
 // order; within the 64, lanes with the same digit find each other with 8 ballots, the lowest ones first; per wave and
 // digit a running count in LDS gives the rank among the wave's earlier keys; after an exclusive scan of the 16 x 256
 // counts in (digit, wave) order every key knows its place.  The keys stay in registers between the count and the
 // scatter, so one array is sorted in place.
 //
-// LDS (forward): SA 64 KiB | RK 64 KiB | counts 8 KiB | 256 B.  RK's space first holds the block itself (the two-byte
+// LDS (forward): SA 64 KiB | RK 64 KiB | counts 8 KiB | 256 B | list 22 KiB.  RK's space first holds the block itself (the two-byte
 // keys are bytes of it) and at the end again (the column is gathered from it); SA's space ends as the staging buffer
 // the 32770 output bytes leave from in aligned 16-byte pieces.  One workgroup per CU.
 #pragma once
@@ -42,7 +47,11 @@
 #define RCX_BWT_FWD_RK 65536u
 #define RCX_BWT_FWD_CNT 131072u
 #define RCX_BWT_FWD_MISC (131072u + 8192u)
-#define RCX_BWT_FWD_LDS (RCX_BWT_FWD_MISC + 256u)
+#define RCX_BWT_FWD_LIST (RCX_BWT_FWD_MISC + 256u)
+#define RCX_BWT_FINAL 0x8000u  /* in RK: the rotation is alone in its group, its row is final */
+#define RCX_BWT_LIST_BIG 11u   /* a list of up to 16 waves x 11 x 64 = 11264 rotations ... */
+#define RCX_BWT_LIST_SMALL 3u  /* ... or of up to 3072 */
+#define RCX_BWT_FWD_LDS (RCX_BWT_FWD_LIST + 2u * 1024u * RCX_BWT_LIST_BIG)
 
 #define RCX_BWT_INV_NEXT 0u
 #define RCX_BWT_INV_ENC 65536u                 /* 32770 bytes + up to 15 of alignment */
@@ -127,10 +136,10 @@ __device__ __forceinline__ u32 rcx_bwt_block_excl(u32 v, u32* misc)
     return base + incl - v;
 }
 
-// One stable counting pass over arr[0..32767]: the elements end up ordered by their digit, equal digits in the order
-// they were in.  ELEM(x) turns what is read from arr into the element that is stored back, DIGIT(e) is its digit.
-// Both run on whole batches of 32 per lane before anything is counted, so their LDS reads overlap.
-template <class Elem, class Digit>
+// One stable counting pass over arr[0 .. 1024 ITERS): the elements end up ordered by their digit, equal digits in the
+// order they were in.  ELEM(x) turns what is read from arr into the element that is stored back, DIGIT(e) is its
+// digit.  Both run on whole batches of ITERS per lane before anything is counted, so their LDS reads overlap.
+template <u32 ITERS, class Elem, class Digit>
 __device__ __forceinline__ void rcx_bwt_pass(uint16_t* arr, uint16_t* cnt, u32* misc, Elem elem, Digit digit)
 {
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
@@ -140,22 +149,24 @@ __device__ __forceinline__ void rcx_bwt_pass(uint16_t* arr, uint16_t* cnt, u32* 
     mine[lane + 64] = 0;
     mine[lane + 128] = 0;
     mine[lane + 192] = 0;
-    u32 held[32]; // element | rank among the wave's earlier keys with the same digit << 16
-    u32 digits[8];
-    const uint16_t* in = arr + 2048u * w + lane;
+    u32 held[ITERS]; // element | rank among the wave's earlier keys with the same digit << 16
+    u32 digits[(ITERS + 3) / 4];
+    const uint16_t* in = arr + 64u * ITERS * w + lane;
 #pragma unroll
-    for (u32 it = 0; it < 32; ++it) held[it] = in[64u * it];
+    for (u32 it = 0; it < ITERS; ++it) held[it] = in[64u * it];
 #pragma unroll
-    for (u32 it = 0; it < 32; ++it) held[it] = elem(held[it]);
+    for (u32 it = 0; it < ITERS; ++it) held[it] = elem(held[it]);
     {
-        u32 dg[32];
+        u32 dg[ITERS];
 #pragma unroll
-        for (u32 it = 0; it < 32; ++it) dg[it] = digit(held[it]);
+        for (u32 it = 0; it < ITERS; ++it) dg[it] = digit(held[it]);
 #pragma unroll
-        for (u32 q = 0; q < 8; ++q) digits[q] = dg[4 * q] | (dg[4 * q + 1] << 8) | (dg[4 * q + 2] << 16) | (dg[4 * q + 3] << 24);
+        for (u32 q = 0; q < (ITERS + 3) / 4; ++q) digits[q] = 0;
+#pragma unroll
+        for (u32 it = 0; it < ITERS; ++it) digits[it >> 2] |= dg[it] << (8u * (it & 3u));
     }
 #pragma unroll
-    for (u32 it = 0; it < 32; ++it) {
+    for (u32 it = 0; it < ITERS; ++it) {
         const u32 d = (digits[it >> 2] >> (8u * (it & 3u))) & 0xFFu;
         u32 below, total;
         rcx_bwt_match8(d, below, total);
@@ -175,24 +186,20 @@ __device__ __forceinline__ void rcx_bwt_pass(uint16_t* arr, uint16_t* cnt, u32* 
     }
     __syncthreads();
 #pragma unroll
-    for (u32 q = 0; q < 8; ++q) asm volatile("" : "+v"(digits[q])); // (addresses are formed again here, not kept from above)
+    for (u32 q = 0; q < (ITERS + 3) / 4; ++q) asm volatile("" : "+v"(digits[q])); // (addresses are formed again here, not kept from above)
     {
-        u32 base[32];
+        u32 base[ITERS];
 #pragma unroll
-        for (u32 it = 0; it < 32; ++it) base[it] = mine[(digits[it >> 2] >> (8u * (it & 3u))) & 0xFFu];
+        for (u32 it = 0; it < ITERS; ++it) base[it] = mine[(digits[it >> 2] >> (8u * (it & 3u))) & 0xFFu];
 #pragma unroll
-        for (u32 it = 0; it < 32; ++it) arr[base[it] + (held[it] >> 16)] = (uint16_t)held[it];
+        for (u32 it = 0; it < ITERS; ++it) arr[base[it] + (held[it] >> 16)] = (uint16_t)held[it];
     }
     __syncthreads();
 }
 
-// New groups: row k starts one if KEY(SA[k]) differs from KEY(SA[k - 1]); RK[SA[k]] = the first row of k's group.
-// Thread t looks at rows [32 t, 32 t + 32).  Returns the number of groups.  misc: 32 dwords.
-template <class Key>
-__device__ __forceinline__ u32 rcx_bwt_rerank(const uint16_t* sa, uint16_t* rk, u32* misc, Key key)
+// 32 consecutive rows of SA into registers
+__device__ __forceinline__ void rcx_bwt_rows32(const uint16_t* sa, u32 k0, u32 (&s)[32])
 {
-    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, k0 = 32u * tid;
-    u32 s[32];
 #pragma unroll
     for (u32 q = 0; q < 4; ++q) {
         const U4 v = reinterpret_cast<const U4*>(sa + k0)[q];
@@ -205,6 +212,55 @@ __device__ __forceinline__ u32 rcx_bwt_rerank(const uint16_t* sa, uint16_t* rk, 
         s[8 * q + 6] = v.w & 0xFFFFu;
         s[8 * q + 7] = v.w >> 16;
     }
+}
+
+// exclusive running maximum over the workgroup (values >= 0, "nothing yet" = 0); misc: 16 dwords
+__device__ __forceinline__ u32 rcx_bwt_block_excl_max(u32 v, u32* misc)
+{
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    u32 run = v;
+#pragma unroll
+    for (u32 o = 1; o < 64; o <<= 1) {
+        const u32 t = (u32)__shfl_up((int)run, o, 64);
+        if (lane >= o) run = run > t ? run : t;
+    }
+    const u32 before = (u32)__shfl_up((int)run, 1, 64);
+    if (lane == 63) misc[w] = run;
+    __syncthreads();
+    u32 carry = lane ? before : 0u;
+#pragma unroll
+    for (u32 i = 0; i < RCX_BWT_WAVES; ++i) {
+        const u32 m = misc[i];
+        if (i < w) carry = carry > m ? carry : m;
+    }
+    __syncthreads();
+    return carry;
+}
+
+// sum over the workgroup; misc: 16 dwords
+__device__ __forceinline__ u32 rcx_bwt_block_sum(u32 v, u32* misc)
+{
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+#pragma unroll
+    for (u32 o = 32; o > 0; o >>= 1) v += (u32)__shfl_xor((int)v, o, 64);
+    if (lane == 0) misc[w] = v;
+    __syncthreads();
+    u32 all = 0;
+#pragma unroll
+    for (u32 i = 0; i < RCX_BWT_WAVES; ++i) all += misc[i];
+    __syncthreads();
+    return all;
+}
+
+// New groups: row k starts one if KEY(SA[k]) differs from KEY(SA[k - 1]); RK[SA[k]] = the first row of k's group, with
+// RCX_BWT_FINAL if the group is that one row.  Thread t looks at rows [32 t, 32 t + 32).  Returns the number of groups,
+// `open` = the rotations that are not final.  misc: 48 dwords.
+template <class Key>
+__device__ __forceinline__ u32 rcx_bwt_rerank(const uint16_t* sa, uint16_t* rk, u32* misc, Key key, u32& open)
+{
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, k0 = 32u * tid;
+    u32 s[32];
+    rcx_bwt_rows32(sa, k0, s);
     u32 prev = key((u32)sa[(k0 + RCX_BWT_MASK) & RCX_BWT_MASK]);
     u32 bits = 0;
 #pragma unroll
@@ -214,34 +270,127 @@ __device__ __forceinline__ u32 rcx_bwt_rerank(const uint16_t* sa, uint16_t* rk, 
         prev = kk;
     }
     if (tid == 0) bits |= 1u;
+    // does the row behind this thread's start a group?  (behind the last row: yes)
+    const u32 behind = (tid == RCX_BWT_THREADS - 1u || key((u32)sa[(k0 + 32u) & RCX_BWT_MASK]) != prev) ? 1u : 0u;
+    const u32 alone = bits & ((bits >> 1) | (behind << 31));
     // the last group start at or before each row: inside the thread from `bits`, before it a running maximum
     const u32 last = bits ? k0 + 31u - (u32)__clz(bits) : 0u;
-    u32 run = last, sum = (u32)__popc(bits);
+    u32 run = last, sum = (u32)__popc(bits) | ((32u - (u32)__popc(alone)) << 16);
 #pragma unroll
     for (u32 o = 1; o < 64; o <<= 1) {
         const u32 t = (u32)__shfl_up((int)run, o, 64);
         if (lane >= o) run = run > t ? run : t;
     }
 #pragma unroll
-    for (u32 o = 32; o > 0; o >>= 1) sum += (u32)__shfl_xor((int)sum, o, 64);
+    for (u32 o = 32; o > 0; o >>= 1) sum += (u32)__shfl_xor((int)sum, o, 64); // (two 16-bit sums: at most 2048 each per wave)
     const u32 before = (u32)__shfl_up((int)run, 1, 64);
     if (lane == 63) misc[w] = run;
-    if (lane == 0) misc[16 + w] = sum;
+    if (lane == 0) {
+        misc[16 + w] = sum & 0xFFFFu;
+        misc[32 + w] = sum >> 16;
+    }
     __syncthreads(); // (every key has been read: RK may be rewritten)
-    u32 carry = lane ? before : 0u, groups = 0;
+    u32 carry = lane ? before : 0u, groups = 0, left = 0;
 #pragma unroll
     for (u32 i = 0; i < RCX_BWT_WAVES; ++i) {
         const u32 m = misc[i];
         if (i < w) carry = carry > m ? carry : m;
         groups += misc[16 + i];
+        left += misc[32 + i];
     }
 #pragma unroll
     for (u32 i = 0; i < 32; ++i) {
         const u32 m = bits & ((2u << i) - 1u);
-        rk[s[i]] = (uint16_t)(m ? k0 + 31u - (u32)__clz(m) : carry);
+        rk[s[i]] = (uint16_t)((m ? k0 + 31u - (u32)__clz(m) : carry) | (((alone >> i) & 1u) ? RCX_BWT_FINAL : 0u));
     }
     __syncthreads();
+    open = left;
     return groups;
+}
+
+// The rotations SA[k] - h that are not final, in the order of k, into lst[0 .. count); lst is padded with 0xFFFF up to
+// `padded`.  Returns the count.  misc: 24 dwords.
+__device__ __forceinline__ u32 rcx_bwt_collect(const uint16_t* sa, const uint16_t* rk, uint16_t* lst, u32* misc, u32 h, u32 padded)
+{
+    const u32 tid = threadIdx.x, k0 = 32u * tid;
+    u32 s[32];
+    rcx_bwt_rows32(sa, k0, s);
+    u32 pick = 0;
+#pragma unroll
+    for (u32 i = 0; i < 32; ++i) {
+        s[i] = (s[i] - h) & RCX_BWT_MASK;
+        pick |= ((u32)rk[s[i]] < RCX_BWT_FINAL ? 1u : 0u) << i;
+    }
+    const u32 mine = (u32)__popc(pick);
+    const u32 at = rcx_bwt_block_excl(mine, misc);
+    if (tid == RCX_BWT_THREADS - 1u) misc[20] = at + mine;
+#pragma unroll
+    for (u32 i = 0; i < 32; ++i)
+        if ((pick >> i) & 1u) lst[at + (u32)__popc(pick & ((1u << i) - 1u))] = (uint16_t)s[i];
+    __syncthreads();
+    const u32 count = misc[20];
+    for (u32 p = count + tid; p < padded; p += RCX_BWT_THREADS) lst[p] = 0xFFFFu;
+    __syncthreads();
+    return count;
+}
+
+// lst[0 .. count) holds the open rotations ordered by group, inside a group by their second h bytes: they go to the
+// rows of their groups in that order, and the groups are split where neighbours differ in RK[. + h].  Thread t handles
+// list entries [L t, L t + L).  splits = how many groups were added, returns the rotations still open.  misc: 16 dwords.
+template <u32 L>
+__device__ __forceinline__ u32 rcx_bwt_place(uint16_t* sa, uint16_t* rk, const uint16_t* lst, u32* misc, u32 h, u32 count, u32& splits)
+{
+    const u32 tid = threadIdx.x, q0 = L * tid;
+    u32 j[L + 2], g[L + 2], k2[L + 2]; // entries q0 - 1 .. q0 + L
+#pragma unroll
+    for (u32 i = 0; i < L + 2; ++i) {
+        const u32 q = q0 + i - 1u;
+        const bool there = q < count; // (q0 - 1 wraps for the first thread)
+        j[i] = there ? (u32)lst[q] : 0u;
+    }
+#pragma unroll
+    for (u32 i = 0; i < L + 2; ++i) {
+        const u32 q = q0 + i - 1u;
+        const bool there = q < count;
+        g[i] = there ? (u32)rk[j[i]] & RCX_BWT_MASK : 0xFFFFFFFFu;
+        k2[i] = there ? (u32)rk[(j[i] + h) & RCX_BWT_MASK] & RCX_BWT_MASK : 0xFFFFFFFFu;
+    }
+    // bit i - 1: entry q0 + i - 1 ... starts an old group / starts a new group (entries past the list count as starts)
+    u32 olds = 0, news = 0;
+#pragma unroll
+    for (u32 i = 1; i < L + 2; ++i) {
+        const u32 q = q0 + i - 1u;
+        const u32 o = (q == 0 || q >= count || g[i] != g[i - 1]) ? 1u : 0u;
+        const u32 n = (o || k2[i] != k2[i - 1]) ? 1u : 0u;
+        olds |= o << (i - 1);
+        news |= n << (i - 1);
+    }
+    const u32 own = (1u << L) - 1u; // this thread's entries
+    u32 in_list = 0;
+#pragma unroll
+    for (u32 i = 0; i < L; ++i) in_list |= (q0 + i < count ? 1u : 0u) << i;
+    // index + 1 of the last old / new start at or before each entry: inside the thread from the bits, before it a running maximum
+    const u32 o_own = olds & own & in_list, n_own = news & own & in_list;
+    const u32 o_before = rcx_bwt_block_excl_max(o_own ? q0 + 32u - (u32)__clz(o_own) : 0u, misc);
+    const u32 n_before = rcx_bwt_block_excl_max(n_own ? q0 + 32u - (u32)__clz(n_own) : 0u, misc);
+    const u32 alone = news & (news >> 1) & own & in_list;
+    const u32 sums = rcx_bwt_block_sum(((u32)__popc(n_own) - (u32)__popc(o_own)) | (((u32)__popc(in_list) - (u32)__popc(alone)) << 16), misc);
+    // (every RK has been read: the barriers above)
+#pragma unroll
+    for (u32 i = 0; i < L; ++i) {
+        if ((in_list >> i) & 1u) {
+            const u32 q = q0 + i;
+            const u32 om = o_own & ((2u << i) - 1u), nm = n_own & ((2u << i) - 1u);
+            const u32 first_old = om ? q0 + 31u - (u32)__clz(om) : o_before - 1u;
+            const u32 first_new = nm ? q0 + 31u - (u32)__clz(nm) : n_before - 1u;
+            const u32 row = g[i + 1] + (q - first_old);
+            sa[row] = (uint16_t)j[i + 1];
+            rk[j[i + 1]] = (uint16_t)((row - (q - first_new)) | (((alone >> i) & 1u) ? RCX_BWT_FINAL : 0u));
+        }
+    }
+    __syncthreads();
+    splits = sums & 0xFFFFu;
+    return sums >> 16;
 }
 
 // ties: [0] = count, then (block, period) pairs of the periodic blocks with a period above 1
@@ -253,6 +402,7 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
     uint16_t* rk = reinterpret_cast<uint16_t*>(lds + RCX_BWT_FWD_RK);
     uint16_t* cnt = reinterpret_cast<uint16_t*>(lds + RCX_BWT_FWD_CNT);
     u32* misc = reinterpret_cast<u32*>(lds + RCX_BWT_FWD_MISC);
+    uint16_t* lst = reinterpret_cast<uint16_t*>(lds + RCX_BWT_FWD_LIST);
     const u32 tid = threadIdx.x;
     for (u64 b = blockIdx.x; b < nblocks; b += gridDim.x) {
         const u8* in = src + b * RCX_BWT_BLOCK;
@@ -266,37 +416,49 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
         __syncthreads();
 #pragma nounroll
         for (u32 second = 1; second < 2; --second)
-            rcx_bwt_pass(sa, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)text[shift + ((e + second) & RCX_BWT_MASK)]; });
-        u32 groups = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return ((u32)text[shift + s] << 8) | text[shift + ((s + 1u) & RCX_BWT_MASK)]; });
-        for (u32 h = 2; groups < RCX_BWT_BLOCK && h < RCX_BWT_BLOCK; h <<= 1) {
+            rcx_bwt_pass<32>(sa, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)text[shift + ((e + second) & RCX_BWT_MASK)]; });
+        u32 open;
+        u32 groups = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return ((u32)text[shift + s] << 8) | text[shift + ((s + 1u) & RCX_BWT_MASK)]; }, open);
+        for (u32 h = 2; open > 0 && h < RCX_BWT_BLOCK; h <<= 1) {
+            if (open > 1024u * RCX_BWT_LIST_BIG) {
 #pragma nounroll
-            for (u32 high = 0; high < 2; ++high) {
-                const u32 back = high ? 0u : h, down = 8u * high;
-                rcx_bwt_pass(sa, cnt, misc, [&](u32 x) { return (x - back) & RCX_BWT_MASK; }, [&](u32 e) { return ((u32)rk[e] >> down) & 0xFFu; });
+                for (u32 high = 0; high < 2; ++high) {
+                    const u32 back = high ? 0u : h, down = 8u * high;
+                    rcx_bwt_pass<32>(sa, cnt, misc, [&](u32 x) { return (x - back) & RCX_BWT_MASK; },
+                                     [&](u32 e) { return (((u32)rk[e] & RCX_BWT_MASK) >> down) & 0xFFu; });
+                }
+                const u32 now = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return (((u32)rk[s] & RCX_BWT_MASK) << 16) | ((u32)rk[(s + h) & RCX_BWT_MASK] & RCX_BWT_MASK); }, open);
+                if (now == groups) break; // nothing split: the block is periodic, `groups` is its period
+                groups = now;
+            } else {
+                const bool big = open > 1024u * RCX_BWT_LIST_SMALL;
+                const u32 count = rcx_bwt_collect(sa, rk, lst, misc, h, 1024u * (big ? RCX_BWT_LIST_BIG : RCX_BWT_LIST_SMALL));
+                // by group: a padding entry (0xFFFF) sorts behind everything
+                const auto same = [](u32 x) { return x; };
+                u32 splits;
+                if (big) {
+#pragma nounroll
+                    for (u32 down = 0; down < 16; down += 8)
+                        rcx_bwt_pass<RCX_BWT_LIST_BIG>(lst, cnt, misc, same, [&](u32 e) { return e == 0xFFFFu ? 0xFFu : (((u32)rk[e & RCX_BWT_MASK] & RCX_BWT_MASK) >> down) & 0xFFu; });
+                    open = rcx_bwt_place<RCX_BWT_LIST_BIG>(sa, rk, lst, misc, h, count, splits);
+                } else {
+#pragma nounroll
+                    for (u32 down = 0; down < 16; down += 8)
+                        rcx_bwt_pass<RCX_BWT_LIST_SMALL>(lst, cnt, misc, same, [&](u32 e) { return e == 0xFFFFu ? 0xFFu : (((u32)rk[e & RCX_BWT_MASK] & RCX_BWT_MASK) >> down) & 0xFFu; });
+                    open = rcx_bwt_place<RCX_BWT_LIST_SMALL>(sa, rk, lst, misc, h, count, splits);
+                }
+                if (splits == 0) break; // periodic (cannot happen with a list this short, but it is the same test)
+                groups += splits;
             }
-            const u32 now = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return ((u32)rk[s] << 16) | rk[(s + h) & RCX_BWT_MASK]; });
-            if (now == groups) break; // nothing split: the block is periodic, `groups` is its period
-            groups = now;
         }
         // the last column (blksort.h:511-518): byte in front of every row's rotation
         u32 s[32];
         {
             const u32 k0 = 32u * tid;
-#pragma unroll
-            for (u32 q = 0; q < 4; ++q) {
-                const U4 v = reinterpret_cast<const U4*>(sa + k0)[q];
-                s[8 * q + 0] = v.x & 0xFFFFu;
-                s[8 * q + 1] = v.x >> 16;
-                s[8 * q + 2] = v.y & 0xFFFFu;
-                s[8 * q + 3] = v.y >> 16;
-                s[8 * q + 4] = v.z & 0xFFFFu;
-                s[8 * q + 5] = v.z >> 16;
-                s[8 * q + 6] = v.w & 0xFFFFu;
-                s[8 * q + 7] = v.w >> 16;
-            }
+            rcx_bwt_rows32(sa, k0, s);
 #pragma unroll
             for (u32 i = 0; i < 32; ++i)
-                if (s[i] == 0) misc[32] = k0 + i;
+                if (s[i] == 0) misc[48] = k0 + i;
         }
         __syncthreads(); // SA is in registers, RK is done with
         (void)rcx_bwt_stage_in(text, in, RCX_BWT_BLOCK);
@@ -307,7 +469,7 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
         for (u32 i = 0; i < 32; ++i) stage[oshift + 32u * tid + i] = text[shift + ((s[i] + RCX_BWT_MASK) & RCX_BWT_MASK)];
         if (tid == 0) {
             // all rotations equal: the reference's sort moves nothing and row 0 stays where it is (rcx_bwt_tie.hpp)
-            const u32 row = groups == 1 ? 0u : misc[32];
+            const u32 row = groups == 1 ? 0u : misc[48];
             stage[oshift + RCX_BWT_BLOCK] = (u8)(row & 0xFFu); // a uint16_t copied on a little-endian host (blksort.h:518)
             stage[oshift + RCX_BWT_BLOCK + 1] = (u8)(row >> 8);
             if (groups > 1 && groups < RCX_BWT_BLOCK) {
@@ -383,7 +545,7 @@ __global__ __launch_bounds__(1024) void rcx_bwt_inv_k(const u8* __restrict__ src
 #pragma unroll
         for (u32 i = 0; i < 32; ++i) next[32u * tid + i] = (uint16_t)(32u * tid + i);
         __syncthreads();
-        rcx_bwt_pass(next, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)col[e]; });
+        rcx_bwt_pass<32>(next, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)col[e]; });
         u32 top = (u32)col[RCX_BWT_BLOCK] | ((u32)col[RCX_BWT_BLOCK + 1] << 8);
         if (top >= RCX_BWT_BLOCK) { // the reference would read outside its arrays (blksort.h:663)
             if (tid == 0) rcx_flag(status, RCX_ST_CORRUPT, b);
