@@ -1062,7 +1062,7 @@ int rcx_bwt_reserve(rcx_ctx* c, uint64_t n)
     }
     const u64 blocks = n / RCX_BWT_BLOCK;
     u64 bytes = c->ties_count * sizeof(u32);
-    const int r = grow(reinterpret_cast<void**>(&c->ties), &bytes, (1 + 2 * blocks + 2) * sizeof(u32));
+    const int r = grow(reinterpret_cast<void**>(&c->ties), &bytes, (RCX_BWT_TIES_HEAD + 2 * blocks + 2) * sizeof(u32));
     c->ties_count = r == RCX_OK ? bytes / sizeof(u32) : 0;
     return r;
 }
@@ -1077,10 +1077,11 @@ int rcx_bwt_encode_device(rcx_ctx* c, const void* d_src, uint64_t n, void* d_dst
     const u64 blocks = n / RCX_BWT_BLOCK;
     const u8* src = static_cast<const u8*>(d_src);
     u8* dst = static_cast<u8*>(d_dst);
-    HIP_TRY(hipMemsetAsync(c->ties, 0, sizeof(u32), s));
+    if (blocks >> 32) return RCX_E_ARG; // (the block counters are 32 bits: 128 TiB)
+    HIP_TRY(hipMemsetAsync(c->ties, 0, 2 * sizeof(u32), s)); // the tie count and the forward kernel's block counter
     if (blocks) {
         Timed t(c, s, RCX_T_BWT_FORWARD);
-        const u32 grid = (u32)(blocks < (1u << 20) ? blocks : (1u << 20));
+        const u32 grid = (u32)(blocks < (u64)c->cus ? blocks : (u64)c->cus); // one workgroup per CU, blocks off a counter
         hipLaunchKernelGGL(rcx_bwt_fwd_k, dim3(grid), dim3(RCX_BWT_THREADS), RCX_BWT_FWD_LDS, s, src, blocks, dst, c->ties, c->status);
         // periodic blocks (rotations that tie) get the row index the reference's sort would leave; usually none
         const u64 most = 2ull * (u64)c->cus;
@@ -1100,12 +1101,14 @@ int rcx_bwt_decode_device(rcx_ctx* c, const void* d_src, uint64_t n, void* d_dst
     int r = rcx_bwt_reserve(c, 0);
     if (r != RCX_OK) return r;
     const u64 blocks = n / RCX_BWT_ENCODED;
+    if (blocks >> 32) return RCX_E_ARG;
+    HIP_TRY(hipMemsetAsync(c->ties + 2, 0, sizeof(u32), s)); // the inverse kernel's block counter
     const u8* src = static_cast<const u8*>(d_src);
     u8* dst = static_cast<u8*>(d_dst);
     if (blocks) {
         Timed t(c, s, RCX_T_BWT_INVERSE);
-        const u32 grid = (u32)(blocks < (1u << 20) ? blocks : (1u << 20));
-        hipLaunchKernelGGL(rcx_bwt_inv_k, dim3(grid), dim3(RCX_BWT_THREADS), RCX_BWT_INV_LDS, s, src, blocks, dst, c->status);
+        const u32 grid = (u32)(blocks < (u64)c->cus ? blocks : (u64)c->cus);
+        hipLaunchKernelGGL(rcx_bwt_inv_k, dim3(grid), dim3(RCX_BWT_THREADS), RCX_BWT_INV_LDS, s, src, blocks, dst, c->ties + 2, c->status);
     }
     const u64 rest = n - blocks * RCX_BWT_ENCODED;
     if (rest) HIP_TRY(hipMemcpyAsync(dst + blocks * RCX_BWT_BLOCK, src + blocks * RCX_BWT_ENCODED, rest, hipMemcpyDeviceToDevice, s));

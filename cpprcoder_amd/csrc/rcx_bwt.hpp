@@ -57,9 +57,17 @@
 #define RCX_BWT_INV_ENC 65536u                 /* 32770 bytes + up to 15 of alignment */
 #define RCX_BWT_INV_OUT (65536u + 32832u)      /* 32768 bytes + up to 15 */
 #define RCX_BWT_INV_CNT (RCX_BWT_INV_OUT + 32800u)
-#define RCX_BWT_INV_JUMP (RCX_BWT_INV_CNT + 8192u) /* u16[1024] */
-#define RCX_BWT_INV_ACC (RCX_BWT_INV_JUMP + 2048u) /* u32[1024] */
-#define RCX_BWT_INV_MISC (RCX_BWT_INV_ACC + 4096u)
+// Pieces walked side by side by one thread: 1, 2 or 4 (a piece then starts at every 32nd, 16th or 8th row).  More and
+// shorter pieces shorten the two walks (the longest piece sets their time: about 250, 120 or 70 steps) but the pointer
+// jumping grows with the number of pieces, and measured it costs more than it saves: inverse of 1 GiB, 1 / 2 / 4 walks:
+// uniform 7.90 / 8.64 / 8.38 ms, Canterbury 10.7 / 13.3 / 15.2 ms, runs 12.3 / 15.4 / 19.4 ms.
+#if !defined(RCX_BWT_WALKS)
+#define RCX_BWT_WALKS 1u
+#endif
+#define RCX_BWT_PIECE_GAP (32u / RCX_BWT_WALKS)
+#define RCX_BWT_JUMP_ROUNDS (RCX_BWT_WALKS == 4u ? 12u : RCX_BWT_WALKS == 2u ? 11u : 10u) /* log2(pieces) */
+#define RCX_BWT_INV_LINK (RCX_BWT_INV_CNT + 8192u) /* u32[1024 RCX_BWT_WALKS] */
+#define RCX_BWT_INV_MISC (RCX_BWT_INV_LINK + 4096u * RCX_BWT_WALKS)
 #define RCX_BWT_INV_LDS (RCX_BWT_INV_MISC + 256u)
 
 #define RCX_BWT_TIE_ROWS 0u
@@ -393,7 +401,11 @@ __device__ __forceinline__ u32 rcx_bwt_place(uint16_t* sa, uint16_t* rk, const u
     return sums >> 16;
 }
 
-// ties: [0] = count, then (block, period) pairs of the periodic blocks with a period above 1
+// The grid is one workgroup per CU; each takes the next block off a counter until none is left (a workgroup's 158 KiB
+// of LDS would otherwise be handed out again for every block: measured 9 us a block).
+// ties: [0] = count of periodic blocks with a period above 1, [1] = the forward kernel's block counter, [2] = the
+// inverse kernel's, [3] unused, then the (block, period) pairs
+#define RCX_BWT_TIES_HEAD 4u
 __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src, u64 nblocks, u8* __restrict__ dst, u32* __restrict__ ties, u32* status)
 {
     extern __shared__ __attribute__((aligned(16))) u8 rcx_bwt_lds[];
@@ -404,7 +416,11 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
     u32* misc = reinterpret_cast<u32*>(lds + RCX_BWT_FWD_MISC);
     uint16_t* lst = reinterpret_cast<uint16_t*>(lds + RCX_BWT_FWD_LIST);
     const u32 tid = threadIdx.x;
-    for (u64 b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    for (;;) {
+        if (tid == 0) misc[49] = atomicAdd(&ties[1], 1u);
+        __syncthreads();
+        const u64 b = misc[49];
+        if (b >= nblocks) break;
         const u8* in = src + b * RCX_BWT_BLOCK;
         u8* out = dst + b * RCX_BWT_ENCODED;
         u8* text = lds + RCX_BWT_FWD_RK;
@@ -414,11 +430,25 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
 #pragma unroll
         for (u32 i = 0; i < 32; ++i) sa[32u * tid + i] = (uint16_t)(32u * tid + i);
         __syncthreads();
+#if defined(RCX_BWT_PROBE_NO_SORT) /* diagnostic build: what everything around the sort costs (the output is NOT the transform) */
+        u32 open = 0, groups = RCX_BWT_BLOCK;
+        if (src == nullptr) {
+#endif
 #pragma nounroll
         for (u32 second = 1; second < 2; --second)
             rcx_bwt_pass<32>(sa, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)text[shift + ((e + second) & RCX_BWT_MASK)]; });
+#if defined(RCX_BWT_PROBE_PASSES) /* diagnostic build: a stable pass by the same digit again changes nothing, it only costs its time */
+#pragma nounroll
+        for (u32 again = 0; again < RCX_BWT_PROBE_PASSES; ++again)
+            rcx_bwt_pass<32>(sa, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)text[shift + (e & RCX_BWT_MASK)]; });
+#endif
+#if defined(RCX_BWT_PROBE_NO_SORT)
+        groups = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return ((u32)text[shift + s] << 8) | text[shift + ((s + 1u) & RCX_BWT_MASK)]; }, open);
+        }
+#else
         u32 open;
         u32 groups = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return ((u32)text[shift + s] << 8) | text[shift + ((s + 1u) & RCX_BWT_MASK)]; }, open);
+#endif
         for (u32 h = 2; open > 0 && h < RCX_BWT_BLOCK; h <<= 1) {
             if (open > 1024u * RCX_BWT_LIST_BIG) {
 #pragma nounroll
@@ -451,6 +481,11 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
                 groups += splits;
             }
         }
+#if defined(RCX_BWT_PROBE_RERANKS) /* diagnostic build, data whose rows are all final by now: the same ranks again, for their time */
+#pragma nounroll
+        for (u32 again = 0; again < RCX_BWT_PROBE_RERANKS; ++again)
+            (void)rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return (((u32)rk[s] & RCX_BWT_MASK) << 16) | ((u32)rk[(s + 2u) & RCX_BWT_MASK] & RCX_BWT_MASK); }, open);
+#endif
         // the last column (blksort.h:511-518): byte in front of every row's rotation
         u32 s[32];
         {
@@ -477,8 +512,8 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
                     rcx_flag(status, RCX_ST_CORRUPT, b); // a period divides 32768: anything else is a bug here, not data
                 } else {
                     const u32 at = atomicAdd(&ties[0], 1u);
-                    ties[1 + 2 * at] = (u32)b;
-                    ties[2 + 2 * at] = groups;
+                    ties[RCX_BWT_TIES_HEAD + 2 * at] = (u32)b;
+                    ties[RCX_BWT_TIES_HEAD + 2 * at + 1] = groups;
                 }
             }
         }
@@ -498,8 +533,8 @@ __global__ __launch_bounds__(64) void rcx_bwt_tie_k(const u8* __restrict__ src, 
     const u32 lane = threadIdx.x;
     const u32 count = ties[0];
     for (u32 i = blockIdx.x; i < count; i += gridDim.x) {
-        const u64 b = ties[1 + 2 * i];
-        const u32 p = ties[2 + 2 * i];
+        const u64 b = ties[RCX_BWT_TIES_HEAD + 2 * i];
+        const u32 p = ties[RCX_BWT_TIES_HEAD + 2 * i + 1];
         const u8* in = src + b * RCX_BWT_BLOCK;
         for (u32 r = lane; r < RCX_BWT_BLOCK; r += 64) rows[r] = (uint16_t)r;
         for (u32 r = lane; r < p; r += 64) word[r] = in[r];
@@ -525,17 +560,20 @@ __global__ __launch_bounds__(64) void rcx_bwt_tie_k(const u8* __restrict__ src, 
 // second walk writes the bytes where they belong.  `next` is a permutation whatever the input, so every walk ends;
 // if the walk from next[top] closes after C < 32768 steps (a periodic block, or garbage) the reference keeps going
 // round, and so do the writes here (position + m C).
-__global__ __launch_bounds__(1024) void rcx_bwt_inv_k(const u8* __restrict__ src, u64 nblocks, u8* __restrict__ dst, u32* status)
+__global__ __launch_bounds__(1024) void rcx_bwt_inv_k(const u8* __restrict__ src, u64 nblocks, u8* __restrict__ dst, u32* __restrict__ work, u32* status)
 {
     extern __shared__ __attribute__((aligned(16))) u8 rcx_bwt_lds[];
     u8* lds = rcx_bwt_lds;
     uint16_t* next = reinterpret_cast<uint16_t*>(lds + RCX_BWT_INV_NEXT);
     uint16_t* cnt = reinterpret_cast<uint16_t*>(lds + RCX_BWT_INV_CNT);
-    uint16_t* jump = reinterpret_cast<uint16_t*>(lds + RCX_BWT_INV_JUMP);
-    u32* acc = reinterpret_cast<u32*>(lds + RCX_BWT_INV_ACC);
+    u32* link = reinterpret_cast<u32*>(lds + RCX_BWT_INV_LINK);
     u32* misc = reinterpret_cast<u32*>(lds + RCX_BWT_INV_MISC);
     const u32 tid = threadIdx.x;
-    for (u64 b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    for (;;) {
+        if (tid == 0) misc[49] = atomicAdd(work, 1u);
+        __syncthreads();
+        const u64 b = misc[49];
+        if (b >= nblocks) break;
         const u8* in = src + b * RCX_BWT_ENCODED;
         u8* out = dst + b * RCX_BWT_BLOCK;
         u8* enc = lds + RCX_BWT_INV_ENC;
@@ -552,41 +590,78 @@ __global__ __launch_bounds__(1024) void rcx_bwt_inv_k(const u8* __restrict__ src
             top &= RCX_BWT_MASK;
         }
         const u32 x0 = next[top];
-        const u32 residue = x0 & 31u, first = x0 >> 5;
-        const u32 start = residue + 32u * tid;
-        u32 steps = 0, r = start;
-        do {
-            r = next[r];
-            ++steps;
-        } while ((r & 31u) != residue && steps < RCX_BWT_BLOCK); // (a permutation comes back to its start: the bound never cuts in)
-        const u32 into = r >> 5;
-        // distance from every piece to the first one along the links (the first piece is made a sink)
-        jump[tid] = (uint16_t)(tid == first ? first : into);
-        acc[tid] = tid == first ? 0u : steps;
+        // piece v starts at row residue + RCX_BWT_PIECE_GAP v; thread t walks pieces t, t + 1024, ... side by side
+        const u32 residue = x0 & (RCX_BWT_PIECE_GAP - 1u), first = x0 / RCX_BWT_PIECE_GAP;
+        u32 r[RCX_BWT_WALKS], steps[RCX_BWT_WALKS];
+#pragma unroll
+        for (u32 u = 0; u < RCX_BWT_WALKS; ++u) {
+            r[u] = residue + RCX_BWT_PIECE_GAP * (tid + RCX_BWT_THREADS * u);
+            steps[u] = 0;
+        }
+        for (u32 going = (1u << RCX_BWT_WALKS) - 1u; going != 0;) {
+#pragma unroll
+            for (u32 u = 0; u < RCX_BWT_WALKS; ++u) {
+                if ((going >> u) & 1u) {
+                    r[u] = next[r[u]];
+                    ++steps[u];
+                    // (a permutation comes back to its start: the bound on the steps never cuts in)
+                    if ((r[u] & (RCX_BWT_PIECE_GAP - 1u)) == residue || steps[u] >= RCX_BWT_BLOCK) going &= ~(1u << u);
+                }
+            }
+        }
+        // distance from every piece to the first one along the links (the first piece is made a sink): pointer jumping
+        // on one word per piece, link << 16 | distance (16 bits hold every distance along the walk, at most 32768;
+        // off the walk they may wrap into nothing that is used: the link field is re-masked)
+        u32 mine[RCX_BWT_WALKS];
+#pragma unroll
+        for (u32 u = 0; u < RCX_BWT_WALKS; ++u) {
+            const u32 v = tid + RCX_BWT_THREADS * u;
+            mine[u] = v == first ? first << 16 : ((r[u] / RCX_BWT_PIECE_GAP) << 16) | steps[u];
+            link[v] = mine[u];
+        }
         __syncthreads();
 #pragma nounroll
-        for (u32 round = 0; round < 10; ++round) {
-            const u32 j = jump[tid];
-            const u32 a = acc[tid] + acc[j];
-            const u32 jj = jump[j];
+        for (u32 round = 0; round < RCX_BWT_JUMP_ROUNDS; ++round) {
+#pragma unroll
+            for (u32 u = 0; u < RCX_BWT_WALKS; ++u) {
+                const u32 there = link[mine[u] >> 16];
+                mine[u] = (there & 0xFFFF0000u) | ((mine[u] + there) & 0xFFFFu);
+            }
             __syncthreads();
-            jump[tid] = (uint16_t)jj;
-            acc[tid] = a;
+#pragma unroll
+            for (u32 u = 0; u < RCX_BWT_WALKS; ++u) link[tid + RCX_BWT_THREADS * u] = mine[u];
             __syncthreads();
         }
-        if (tid == first) misc[0] = steps + (into == first ? 0u : acc[into]); // the length of the whole walk's cycle
+#pragma unroll
+        for (u32 u = 0; u < RCX_BWT_WALKS; ++u) {
+            const u32 v = tid + RCX_BWT_THREADS * u;
+            const u32 into = r[u] / RCX_BWT_PIECE_GAP;
+            if (v == first) misc[0] = steps[u] + (into == first ? 0u : link[into] & 0xFFFFu); // the length of the whole walk's cycle
+        }
         __syncthreads();
         const u32 cycle = misc[0];
-        const bool on_walk = tid == first || jump[tid] == first;
         u8* stage = lds + RCX_BWT_INV_OUT;
         const u32 oshift = (u32)(reinterpret_cast<uintptr_t>(out) & 15u);
-        if (on_walk) {
-            const u32 at = tid == first ? 0u : cycle - acc[tid];
-            r = start;
-            for (u32 i = 0; i < steps; ++i) {
-                const u8 c = col[r];
-                for (u32 p = at + i; p < RCX_BWT_BLOCK; p += cycle) stage[oshift + p] = c;
-                r = next[r];
+        {
+            u32 at[RCX_BWT_WALKS], left[RCX_BWT_WALKS], most = 0;
+#pragma unroll
+            for (u32 u = 0; u < RCX_BWT_WALKS; ++u) {
+                const u32 v = tid + RCX_BWT_THREADS * u;
+                const bool on_walk = v == first || (mine[u] >> 16) == first;
+                at[u] = v == first ? 0u : cycle - (mine[u] & 0xFFFFu);
+                left[u] = on_walk ? steps[u] : 0u;
+                most = most > left[u] ? most : left[u];
+                r[u] = residue + RCX_BWT_PIECE_GAP * v;
+            }
+            for (u32 i = 0; i < most; ++i) {
+#pragma unroll
+                for (u32 u = 0; u < RCX_BWT_WALKS; ++u) {
+                    if (i < left[u]) {
+                        const u8 c = col[r[u]];
+                        for (u32 p = at[u] + i; p < RCX_BWT_BLOCK; p += cycle) stage[oshift + p] = c;
+                        r[u] = next[r[u]];
+                    }
+                }
             }
         }
         __syncthreads();
