@@ -75,13 +75,24 @@
 #define RCX_BWT_TIE_STACK (65536u + 16384u)
 #define RCX_BWT_TIE_LDS (RCX_BWT_TIE_STACK + RCX_TIE_STACK * 16u + 64u)
 
+// threadIdx.x as a value the compiler treats as new each time: what is computed from it (row numbers, list positions,
+// LDS addresses: one multiply-add each) is then computed where it is used.  Otherwise all of it is hoisted out of the
+// loop over blocks, does not fit the 128 registers a lane of a 16-wave workgroup has, and goes through scratch memory
+// (measured: 27 GiB of HBM traffic for 1 GiB of blocks).
+__device__ __forceinline__ u32 rcx_bwt_tid()
+{
+    u32 t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 // ---------------------------------------------------------------------------
 // global <-> LDS copies of one block.  The LDS image starts at lds + (address & 15), so that both sides of the 16-byte
 // pieces in the middle are aligned whatever the caller's pointer is; a few threads move the ragged ends bytewise.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ u32 rcx_bwt_stage_in(u8* lds, const u8* g, u32 bytes)
 {
-    const u32 tid = threadIdx.x;
+    const u32 tid = rcx_bwt_tid();
     const u32 shift = (u32)(reinterpret_cast<uintptr_t>(g) & 15u);
     const u32 head = (16u - shift) & 15u;
     const u32 pieces = (bytes - head) >> 4, tail = (bytes - head) & 15u;
@@ -94,7 +105,7 @@ __device__ __forceinline__ u32 rcx_bwt_stage_in(u8* lds, const u8* g, u32 bytes)
 // the image must have been built at lds + (g & 15)
 __device__ __forceinline__ void rcx_bwt_stage_out(u8* g, const u8* lds, u32 bytes)
 {
-    const u32 tid = threadIdx.x;
+    const u32 tid = rcx_bwt_tid();
     const u32 shift = (u32)(reinterpret_cast<uintptr_t>(g) & 15u);
     const u32 head = (16u - shift) & 15u;
     const u32 pieces = (bytes - head) >> 4, tail = (bytes - head) & 15u;
@@ -122,16 +133,42 @@ __device__ __forceinline__ void rcx_bwt_match8(u32 d, u32& below, u32& total)
     total = (u32)__popc(lo) + (u32)__popc(hi);
 }
 
+// Inclusive scans over the 64 lanes with DPP moves (no LDS, no index registers): each lane first gathers the three
+// lanes before it in its row of 16, then whole quarters and halves of the row, then the totals of the rows before.
+// A lane the move does not reach sees 0, the identity of both operations.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ u32 rcx_bwt_dpp0(u32 v)
+{
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+__device__ __forceinline__ u32 rcx_bwt_wave_incl_sum(u32 v)
+{
+    v += rcx_bwt_dpp0<0x111, 0xF, 0xF>(v) + rcx_bwt_dpp0<0x112, 0xF, 0xF>(v) + rcx_bwt_dpp0<0x113, 0xF, 0xF>(v); // row_shr:1..3
+    v += rcx_bwt_dpp0<0x114, 0xF, 0xE>(v); // row_shr:4, lanes 4..15 of a row
+    v += rcx_bwt_dpp0<0x118, 0xF, 0xC>(v); // row_shr:8, lanes 8..15
+    v += rcx_bwt_dpp0<0x142, 0xA, 0xF>(v); // row_bcast:15 into rows 1 and 3
+    v += rcx_bwt_dpp0<0x143, 0xC, 0xF>(v); // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ u32 rcx_bwt_max(u32 a, u32 b) { return a > b ? a : b; }
+__device__ __forceinline__ u32 rcx_bwt_wave_incl_max(u32 v)
+{
+    v = rcx_bwt_max(rcx_bwt_max(v, rcx_bwt_dpp0<0x111, 0xF, 0xF>(v)), rcx_bwt_max(rcx_bwt_dpp0<0x112, 0xF, 0xF>(v), rcx_bwt_dpp0<0x113, 0xF, 0xF>(v)));
+    v = rcx_bwt_max(v, rcx_bwt_dpp0<0x114, 0xF, 0xE>(v));
+    v = rcx_bwt_max(v, rcx_bwt_dpp0<0x118, 0xF, 0xC>(v));
+    v = rcx_bwt_max(v, rcx_bwt_dpp0<0x142, 0xA, 0xF>(v));
+    v = rcx_bwt_max(v, rcx_bwt_dpp0<0x143, 0xC, 0xF>(v));
+    return v;
+}
+// the value of the lane before (0 for lane 0): wave_shr:1
+__device__ __forceinline__ u32 rcx_bwt_wave_prev(u32 v) { return rcx_bwt_dpp0<0x138, 0xF, 0xF>(v); }
+__device__ __forceinline__ u32 rcx_bwt_wave_last(u32 v) { return (u32)__builtin_amdgcn_readlane((int)v, 63); }
+
 // exclusive prefix sum over the workgroup (all 1024 threads call it); misc: 16 dwords
 __device__ __forceinline__ u32 rcx_bwt_block_excl(u32 v, u32* misc)
 {
     const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    u32 incl = v;
-#pragma unroll
-    for (u32 o = 1; o < 64; o <<= 1) {
-        const u32 t = (u32)__shfl_up((int)incl, o, 64);
-        if (lane >= o) incl += t;
-    }
+    const u32 incl = rcx_bwt_wave_incl_sum(v);
     if (lane == 63) misc[w] = incl;
     __syncthreads();
     u32 base = 0;
@@ -150,7 +187,7 @@ __device__ __forceinline__ u32 rcx_bwt_block_excl(u32 v, u32* misc)
 template <u32 ITERS, class Elem, class Digit>
 __device__ __forceinline__ void rcx_bwt_pass(uint16_t* arr, uint16_t* cnt, u32* misc, Elem elem, Digit digit)
 {
-    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const u32 tid = rcx_bwt_tid(), lane = tid & 63u, w = tid >> 6;
     uint16_t* mine = cnt + 256u * w;
     // (u16 stores: a dword store through another pointer type may legally be moved behind the u16 reads below)
     mine[lane] = 0;
@@ -226,16 +263,11 @@ __device__ __forceinline__ void rcx_bwt_rows32(const uint16_t* sa, u32 k0, u32 (
 __device__ __forceinline__ u32 rcx_bwt_block_excl_max(u32 v, u32* misc)
 {
     const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    u32 run = v;
-#pragma unroll
-    for (u32 o = 1; o < 64; o <<= 1) {
-        const u32 t = (u32)__shfl_up((int)run, o, 64);
-        if (lane >= o) run = run > t ? run : t;
-    }
-    const u32 before = (u32)__shfl_up((int)run, 1, 64);
+    const u32 run = rcx_bwt_wave_incl_max(v);
+    const u32 before = rcx_bwt_wave_prev(run);
     if (lane == 63) misc[w] = run;
     __syncthreads();
-    u32 carry = lane ? before : 0u;
+    u32 carry = before;
 #pragma unroll
     for (u32 i = 0; i < RCX_BWT_WAVES; ++i) {
         const u32 m = misc[i];
@@ -249,9 +281,8 @@ __device__ __forceinline__ u32 rcx_bwt_block_excl_max(u32 v, u32* misc)
 __device__ __forceinline__ u32 rcx_bwt_block_sum(u32 v, u32* misc)
 {
     const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-#pragma unroll
-    for (u32 o = 32; o > 0; o >>= 1) v += (u32)__shfl_xor((int)v, o, 64);
-    if (lane == 0) misc[w] = v;
+    v = rcx_bwt_wave_incl_sum(v);
+    if (lane == 63) misc[w] = v;
     __syncthreads();
     u32 all = 0;
 #pragma unroll
@@ -266,7 +297,7 @@ __device__ __forceinline__ u32 rcx_bwt_block_sum(u32 v, u32* misc)
 template <class Key>
 __device__ __forceinline__ u32 rcx_bwt_rerank(const uint16_t* sa, uint16_t* rk, u32* misc, Key key, u32& open)
 {
-    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, k0 = 32u * tid;
+    const u32 tid = rcx_bwt_tid(), lane = tid & 63u, w = tid >> 6, k0 = 32u * tid;
     u32 s[32];
     rcx_bwt_rows32(sa, k0, s);
     u32 prev = key((u32)sa[(k0 + RCX_BWT_MASK) & RCX_BWT_MASK]);
@@ -283,22 +314,17 @@ __device__ __forceinline__ u32 rcx_bwt_rerank(const uint16_t* sa, uint16_t* rk, 
     const u32 alone = bits & ((bits >> 1) | (behind << 31));
     // the last group start at or before each row: inside the thread from `bits`, before it a running maximum
     const u32 last = bits ? k0 + 31u - (u32)__clz(bits) : 0u;
-    u32 run = last, sum = (u32)__popc(bits) | ((32u - (u32)__popc(alone)) << 16);
-#pragma unroll
-    for (u32 o = 1; o < 64; o <<= 1) {
-        const u32 t = (u32)__shfl_up((int)run, o, 64);
-        if (lane >= o) run = run > t ? run : t;
-    }
-#pragma unroll
-    for (u32 o = 32; o > 0; o >>= 1) sum += (u32)__shfl_xor((int)sum, o, 64); // (two 16-bit sums: at most 2048 each per wave)
-    const u32 before = (u32)__shfl_up((int)run, 1, 64);
-    if (lane == 63) misc[w] = run;
-    if (lane == 0) {
+    const u32 run = rcx_bwt_wave_incl_max(last);
+    // (two 16-bit sums in one word: at most 2048 each per wave)
+    const u32 sum = rcx_bwt_wave_incl_sum((u32)__popc(bits) | ((32u - (u32)__popc(alone)) << 16));
+    const u32 before = rcx_bwt_wave_prev(run);
+    if (lane == 63) {
+        misc[w] = run;
         misc[16 + w] = sum & 0xFFFFu;
         misc[32 + w] = sum >> 16;
     }
     __syncthreads(); // (every key has been read: RK may be rewritten)
-    u32 carry = lane ? before : 0u, groups = 0, left = 0;
+    u32 carry = before, groups = 0, left = 0;
 #pragma unroll
     for (u32 i = 0; i < RCX_BWT_WAVES; ++i) {
         const u32 m = misc[i];
@@ -320,7 +346,7 @@ __device__ __forceinline__ u32 rcx_bwt_rerank(const uint16_t* sa, uint16_t* rk, 
 // `padded`.  Returns the count.  misc: 24 dwords.
 __device__ __forceinline__ u32 rcx_bwt_collect(const uint16_t* sa, const uint16_t* rk, uint16_t* lst, u32* misc, u32 h, u32 padded)
 {
-    const u32 tid = threadIdx.x, k0 = 32u * tid;
+    const u32 tid = rcx_bwt_tid(), k0 = 32u * tid;
     u32 s[32];
     rcx_bwt_rows32(sa, k0, s);
     u32 pick = 0;
@@ -348,7 +374,7 @@ __device__ __forceinline__ u32 rcx_bwt_collect(const uint16_t* sa, const uint16_
 template <u32 L>
 __device__ __forceinline__ u32 rcx_bwt_place(uint16_t* sa, uint16_t* rk, const uint16_t* lst, u32* misc, u32 h, u32 count, u32& splits)
 {
-    const u32 tid = threadIdx.x, q0 = L * tid;
+    const u32 tid = rcx_bwt_tid(), q0 = L * tid;
     u32 j[L + 2], g[L + 2], k2[L + 2]; // entries q0 - 1 .. q0 + L
 #pragma unroll
     for (u32 i = 0; i < L + 2; ++i) {
@@ -427,8 +453,11 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
         const u32 shift = rcx_bwt_stage_in(text, in, RCX_BWT_BLOCK);
         __syncthreads();
         // rows by their first two bytes: the second byte first (rows in index order), then the first
+        {
+            const u32 k0 = 32u * rcx_bwt_tid();
 #pragma unroll
-        for (u32 i = 0; i < 32; ++i) sa[32u * tid + i] = (uint16_t)(32u * tid + i);
+            for (u32 i = 0; i < 32; ++i) sa[k0 + i] = (uint16_t)(k0 + i);
+        }
         __syncthreads();
 #if defined(RCX_BWT_PROBE_NO_SORT) /* diagnostic build: what everything around the sort costs (the output is NOT the transform) */
         u32 open = 0, groups = RCX_BWT_BLOCK;
@@ -489,7 +518,7 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
         // the last column (blksort.h:511-518): byte in front of every row's rotation
         u32 s[32];
         {
-            const u32 k0 = 32u * tid;
+            const u32 k0 = 32u * rcx_bwt_tid();
             rcx_bwt_rows32(sa, k0, s);
 #pragma unroll
             for (u32 i = 0; i < 32; ++i)
@@ -500,8 +529,11 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
         __syncthreads();
         u8* stage = lds + RCX_BWT_FWD_SA;
         const u32 oshift = (u32)(reinterpret_cast<uintptr_t>(out) & 15u);
+        {
+            u8* mine = stage + oshift + 32u * rcx_bwt_tid();
 #pragma unroll
-        for (u32 i = 0; i < 32; ++i) stage[oshift + 32u * tid + i] = text[shift + ((s[i] + RCX_BWT_MASK) & RCX_BWT_MASK)];
+            for (u32 i = 0; i < 32; ++i) mine[i] = text[shift + ((s[i] + RCX_BWT_MASK) & RCX_BWT_MASK)];
+        }
         if (tid == 0) {
             // all rotations equal: the reference's sort moves nothing and row 0 stays where it is (rcx_bwt_tie.hpp)
             const u32 row = groups == 1 ? 0u : misc[48];
@@ -580,8 +612,11 @@ __global__ __launch_bounds__(1024) void rcx_bwt_inv_k(const u8* __restrict__ src
         const u32 shift = rcx_bwt_stage_in(enc, in, RCX_BWT_ENCODED);
         __syncthreads();
         const u8* col = enc + shift;
+        {
+            const u32 k0 = 32u * rcx_bwt_tid();
 #pragma unroll
-        for (u32 i = 0; i < 32; ++i) next[32u * tid + i] = (uint16_t)(32u * tid + i);
+            for (u32 i = 0; i < 32; ++i) next[k0 + i] = (uint16_t)(k0 + i);
+        }
         __syncthreads();
         rcx_bwt_pass<32>(next, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)col[e]; });
         u32 top = (u32)col[RCX_BWT_BLOCK] | ((u32)col[RCX_BWT_BLOCK + 1] << 8);

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 CSV output under gpurun_out/ into the small tracked summaries in profiles/.
 
-    python profiles/summarize.py <tag> <stats_dir> [--config workload=uniform,bytes=1073741824,block=65536] [--pmc name=dir ...]
+    python profiles/summarize.py <tag> <stats_dir> [--side] [--config workload=uniform,bytes=1073741824,block=65536] [--pmc name=dir ...]
+
+--side: a profile of something other than bench.py's default line (e.g. the block sort): profiles/pmc_traffic.json, which
+bench.py replays into roofline.traffic, is left alone.
 
 <stats_dir> is a `rocprofv3 --kernel-trace --stats --output-format csv -d <dir>` directory;
 each --pmc dir is a separate `rocprofv3 --pmc ... --kernel-trace` pass (FETCH_SIZE and WRITE_SIZE
@@ -28,6 +31,9 @@ def short(name: str) -> str:
 def main():
     tag, stats_dir = sys.argv[1], sys.argv[2]
     rest = sys.argv[3:]
+    side = bool(rest) and rest[0] == "--side"
+    if side:
+        rest = rest[1:]
     config = {"workload": "uniform", "bytes": 1 << 30, "block": 65536}  # what bench.py runs by default
     if rest and rest[0] == "--config":
         for kv in rest[1].split(","):
@@ -73,8 +79,9 @@ def main():
         with open(os.path.join(HERE, f"{tag}_pmc.json"), "w") as f:
             json.dump(out, f, indent=1)
         # bench.py reads roofline.traffic from here
-        with open(os.path.join(HERE, "pmc_traffic.json"), "w") as f:
-            json.dump(out, f, indent=1)
+        if not side:
+            with open(os.path.join(HERE, "pmc_traffic.json"), "w") as f:
+                json.dump(out, f, indent=1)
     for r in rows[:6]:
         print(short(r["Name"]), r["Calls"], r["AverageNs"])
     for k, e in out.items():
