@@ -95,6 +95,36 @@ def test_fresh_data_against_the_oracle(ctx):
         assert np.array_equal(ctx.bwt_decode(enc), data), wl
 
 
+def test_many_shapes_against_the_oracle(ctx):
+    """Blocks of many shapes in one buffer: small alphabets, runs, repeats of odd lengths, sorted bytes, and periodic
+    blocks with a few bytes changed (almost all rotations tie over thousands of bytes, none over all of them)."""
+    o = oracle_lib.oracle()
+    mix, blocks = bwt_cases.mix, []
+    for i in range(40):
+        a = 2 + (i * 37) % 255
+        blocks.append((mix(BLOCK, 2000 + i).astype(np.uint32) % a).astype(np.uint8))
+    for i in range(16):
+        lens = 1 + (mix(BLOCK, 2100 + i).astype(np.uint32) % (3 + 40 * i))
+        vals = mix(BLOCK, 2200 + i)
+        blocks.append(np.repeat(vals, lens)[:BLOCK])
+    for i, period in enumerate((3, 5, 7, 100, 1000, 4097, 10000, 16383, 21845)):
+        blocks.append(np.resize(mix(period, 2300 + i), BLOCK).astype(np.uint8))
+    blocks.append(np.sort(mix(BLOCK, 2400)))
+    blocks.append(np.sort(mix(BLOCK, 2401))[::-1].copy())
+    for i, (p, changes) in enumerate(((1, 1), (2, 1), (4, 2), (16, 1), (256, 3), (1024, 1), (4096, 5), (16384, 1))):
+        b = bwt_cases.periodic(p, 2500 + i, 256 if i % 2 else 3).copy()
+        for c in range(changes):
+            b[(7919 * (c + 1) * (i + 3)) % BLOCK] ^= 0x5A
+        blocks.append(b)
+    data = np.concatenate(blocks)
+    enc = ctx.bwt_encode(data)
+    assert ctx.bwt_last_ties() == 0
+    want = o.bwt_encode(data, threads=16)
+    for b in range(len(blocks)):
+        assert np.array_equal(enc[b * ENCODED:(b + 1) * ENCODED], want[b * ENCODED:(b + 1) * ENCODED]), b
+    assert np.array_equal(ctx.bwt_decode(enc), data)
+
+
 def test_inverse_of_arbitrary_bytes_is_the_reference_walk(ctx):
     """BlkSort::decode is defined for any column and any row below 32768 (the walk just follows a permutation, possibly
     round a short cycle): the GPU must follow it the same way."""
