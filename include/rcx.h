@@ -195,6 +195,7 @@ int rcx_dstream_decode(rcx_dstream* stream, const uint8_t* bytes, uint64_t size,
  *   rcx_bwt_decode(_device)   BlkSort::decode (blksort.h:451-462, the source is not modified).  A stored row of 32768 or
  *       more, with which the reference reads outside its arrays, is RCX_E_CORRUPT (through rcx_ctx_sync_status for
  *       the device call).
+ * Source and destination must not overlap (blocks are transformed concurrently).
  * The _device calls take device pointers of any alignment, enqueue on `stream` and do not synchronise; scratch is
  * grown on first use or ahead of time by rcx_bwt_reserve(ctx, n).  Capacities are checked before anything is enqueued
  * (RCX_E_CAPACITY); the host-buffer calls also report the size needed in *dst_size.
