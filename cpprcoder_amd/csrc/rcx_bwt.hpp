@@ -57,17 +57,9 @@
 #define RCX_BWT_INV_ENC 65536u                 /* 32770 bytes + up to 15 of alignment */
 #define RCX_BWT_INV_OUT (65536u + 32832u)      /* 32768 bytes + up to 15 */
 #define RCX_BWT_INV_CNT (RCX_BWT_INV_OUT + 32800u)
-// Pieces walked side by side by one thread: 1, 2 or 4 (a piece then starts at every 32nd, 16th or 8th row).  More and
-// shorter pieces shorten the two walks (the longest piece sets their time: about 250, 120 or 70 steps) but the pointer
-// jumping grows with the number of pieces, and measured it costs more than it saves: inverse of 1 GiB, 1 / 2 / 4 walks:
-// uniform 7.90 / 8.64 / 8.38 ms, Canterbury 10.7 / 13.3 / 15.2 ms, runs 12.3 / 15.4 / 19.4 ms.
-#if !defined(RCX_BWT_WALKS)
-#define RCX_BWT_WALKS 1u
-#endif
-#define RCX_BWT_PIECE_GAP (32u / RCX_BWT_WALKS)
-#define RCX_BWT_JUMP_ROUNDS (RCX_BWT_WALKS == 4u ? 12u : RCX_BWT_WALKS == 2u ? 11u : 10u) /* log2(pieces) */
-#define RCX_BWT_INV_LINK (RCX_BWT_INV_CNT + 8192u) /* u32[1024 RCX_BWT_WALKS] */
-#define RCX_BWT_INV_MISC (RCX_BWT_INV_LINK + 4096u * RCX_BWT_WALKS)
+#define RCX_BWT_INV_LINK (RCX_BWT_INV_CNT + 8192u) /* u32[1024] */
+#define RCX_BWT_INV_MISC (RCX_BWT_INV_LINK + 4096u)
+/* behind the counting pass its 8 KiB of counts hold what the walks note: u32 mark_of[1024] | u16 mark_row[1024] | u16 lens[1024] */
 #define RCX_BWT_INV_LDS (RCX_BWT_INV_MISC + 256u)
 
 #define RCX_BWT_TIE_ROWS 0u
@@ -588,8 +580,12 @@ __global__ __launch_bounds__(64) void rcx_bwt_tie_k(const u8* __restrict__ src, 
 // order): the stable counting pass above with the column byte as the digit.  The reference then walks
 // p = next[top]; out[i] = column[p]; p = next[p] for 32768 steps.  Here the rows congruent to next[top] mod 32 are
 // 1024 starting points; every thread walks from its start to the next start it meets (about 32 steps, all threads at
-// once), the pieces are put in order by pointer jumping over the 1024 (start -> start it ran into) links, and a
-// second walk writes the bytes where they belong.  `next` is a permutation whatever the input, so every walk ends;
+// once; the longest piece, about 250, sets the time), the pieces are put in order by pointer jumping over the 1024
+// (start -> start it ran into) links, and a second walk writes the bytes where they belong -- dealt out in stretches
+// of 32 rows (the first walk notes every 32nd row it passes), so that it does not wait for the longest piece again.
+// More and shorter pieces (2 or 4 walks per thread, a start at every 16th or 8th row) shorten the first walk too, but
+// the pointer jumping grows with the number of pieces and measured it costs more than it saves (inverse of 1 GiB, 1 / 2
+// / 4 walks: uniform 7.90 / 8.64 / 8.38 ms, Canterbury 10.7 / 13.3 / 15.2 ms).  `next` is a permutation whatever the input, so every walk ends;
 // if the walk from next[top] closes after C < 32768 steps (a periodic block, or garbage) the reference keeps going
 // round, and so do the writes here (position + m C).
 __global__ __launch_bounds__(1024) void rcx_bwt_inv_k(const u8* __restrict__ src, u64 nblocks, u8* __restrict__ dst, u32* __restrict__ work, u32* status)
@@ -599,6 +595,9 @@ __global__ __launch_bounds__(1024) void rcx_bwt_inv_k(const u8* __restrict__ src
     uint16_t* next = reinterpret_cast<uint16_t*>(lds + RCX_BWT_INV_NEXT);
     uint16_t* cnt = reinterpret_cast<uint16_t*>(lds + RCX_BWT_INV_CNT);
     u32* link = reinterpret_cast<u32*>(lds + RCX_BWT_INV_LINK);
+    u32* mark_of = reinterpret_cast<u32*>(lds + RCX_BWT_INV_CNT);
+    uint16_t* mark_row = reinterpret_cast<uint16_t*>(lds + RCX_BWT_INV_CNT + 4096u);
+    uint16_t* lens = reinterpret_cast<uint16_t*>(lds + RCX_BWT_INV_CNT + 6144u);
     u32* misc = reinterpret_cast<u32*>(lds + RCX_BWT_INV_MISC);
     const u32 tid = threadIdx.x;
     for (;;) {
@@ -612,6 +611,7 @@ __global__ __launch_bounds__(1024) void rcx_bwt_inv_k(const u8* __restrict__ src
         const u32 shift = rcx_bwt_stage_in(enc, in, RCX_BWT_ENCODED);
         __syncthreads();
         const u8* col = enc + shift;
+        if (tid == 0) misc[40] = 0; // how many stretches the first walk notes (the pass's scans use misc[0..15]; its barriers order this)
         {
             const u32 k0 = 32u * rcx_bwt_tid();
 #pragma unroll
@@ -625,77 +625,62 @@ __global__ __launch_bounds__(1024) void rcx_bwt_inv_k(const u8* __restrict__ src
             top &= RCX_BWT_MASK;
         }
         const u32 x0 = next[top];
-        // piece v starts at row residue + RCX_BWT_PIECE_GAP v; thread t walks pieces t, t + 1024, ... side by side
-        const u32 residue = x0 & (RCX_BWT_PIECE_GAP - 1u), first = x0 / RCX_BWT_PIECE_GAP;
-        u32 r[RCX_BWT_WALKS], steps[RCX_BWT_WALKS];
-#pragma unroll
-        for (u32 u = 0; u < RCX_BWT_WALKS; ++u) {
-            r[u] = residue + RCX_BWT_PIECE_GAP * (tid + RCX_BWT_THREADS * u);
-            steps[u] = 0;
-        }
-        for (u32 going = (1u << RCX_BWT_WALKS) - 1u; going != 0;) {
-#pragma unroll
-            for (u32 u = 0; u < RCX_BWT_WALKS; ++u) {
-                if ((going >> u) & 1u) {
-                    r[u] = next[r[u]];
-                    ++steps[u];
-                    // (a permutation comes back to its start: the bound on the steps never cuts in)
-                    if ((r[u] & (RCX_BWT_PIECE_GAP - 1u)) == residue || steps[u] >= RCX_BWT_BLOCK) going &= ~(1u << u);
-                }
+        // piece v starts at row residue + 32 v and is walked by thread v; every 32nd row on the way is noted, so that
+        // the second walk can be dealt out in stretches of 32 whatever the pieces' lengths are
+        const u32 residue = x0 & 31u, first = x0 >> 5;
+        u32 r = residue + 32u * tid, steps = 0;
+        for (;;) {
+            r = next[r];
+            ++steps;
+            // (a permutation comes back to its start: the bound on the steps never cuts in)
+            if ((r & 31u) == residue || steps >= RCX_BWT_BLOCK) break;
+            if ((steps & 31u) == 0) { // at most 1024 of these in all: the pieces have 32768 rows between them
+                const u32 m = atomicAdd(&misc[40], 1u);
+                mark_row[m] = (uint16_t)r;
+                mark_of[m] = (tid << 16) | (steps >> 5);
             }
         }
+        lens[tid] = (uint16_t)steps; // (32768 = 0x8000 fits)
         // distance from every piece to the first one along the links (the first piece is made a sink): pointer jumping
         // on one word per piece, link << 16 | distance (16 bits hold every distance along the walk, at most 32768;
         // off the walk they may wrap into nothing that is used: the link field is re-masked)
-        u32 mine[RCX_BWT_WALKS];
-#pragma unroll
-        for (u32 u = 0; u < RCX_BWT_WALKS; ++u) {
-            const u32 v = tid + RCX_BWT_THREADS * u;
-            mine[u] = v == first ? first << 16 : ((r[u] / RCX_BWT_PIECE_GAP) << 16) | steps[u];
-            link[v] = mine[u];
-        }
+        u32 mine = tid == first ? first << 16 : ((r >> 5) << 16) | steps;
+        link[tid] = mine;
         __syncthreads();
 #pragma nounroll
-        for (u32 round = 0; round < RCX_BWT_JUMP_ROUNDS; ++round) {
-#pragma unroll
-            for (u32 u = 0; u < RCX_BWT_WALKS; ++u) {
-                const u32 there = link[mine[u] >> 16];
-                mine[u] = (there & 0xFFFF0000u) | ((mine[u] + there) & 0xFFFFu);
-            }
+        for (u32 round = 0; round < 10; ++round) {
+            const u32 there = link[mine >> 16];
+            mine = (there & 0xFFFF0000u) | ((mine + there) & 0xFFFFu);
             __syncthreads();
-#pragma unroll
-            for (u32 u = 0; u < RCX_BWT_WALKS; ++u) link[tid + RCX_BWT_THREADS * u] = mine[u];
+            link[tid] = mine;
             __syncthreads();
         }
-#pragma unroll
-        for (u32 u = 0; u < RCX_BWT_WALKS; ++u) {
-            const u32 v = tid + RCX_BWT_THREADS * u;
-            const u32 into = r[u] / RCX_BWT_PIECE_GAP;
-            if (v == first) misc[0] = steps[u] + (into == first ? 0u : link[into] & 0xFFFFu); // the length of the whole walk's cycle
-        }
+        if (tid == first) misc[41] = steps + ((r >> 5) == first ? 0u : link[r >> 5] & 0xFFFFu); // the length of the whole walk's cycle
         __syncthreads();
-        const u32 cycle = misc[0];
+        const u32 cycle = misc[41], marks = misc[40];
         u8* stage = lds + RCX_BWT_INV_OUT;
         const u32 oshift = (u32)(reinterpret_cast<uintptr_t>(out) & 15u);
-        {
-            u32 at[RCX_BWT_WALKS], left[RCX_BWT_WALKS], most = 0;
-#pragma unroll
-            for (u32 u = 0; u < RCX_BWT_WALKS; ++u) {
-                const u32 v = tid + RCX_BWT_THREADS * u;
-                const bool on_walk = v == first || (mine[u] >> 16) == first;
-                at[u] = v == first ? 0u : cycle - (mine[u] & 0xFFFFu);
-                left[u] = on_walk ? steps[u] : 0u;
-                most = most > left[u] ? most : left[u];
-                r[u] = residue + RCX_BWT_PIECE_GAP * v;
+        // second walk: the head of the thread's own piece, and one noted stretch
+#pragma nounroll
+        for (u32 job = 0; job < 2; ++job) {
+            u32 v = tid, from = residue + 32u * tid, skip = 0;
+            bool have = job == 0;
+            if (job == 1 && tid < marks) {
+                v = mark_of[tid] >> 16;
+                skip = 32u * (mark_of[tid] & 0xFFFFu);
+                from = mark_row[tid];
+                have = true;
             }
-            for (u32 i = 0; i < most; ++i) {
-#pragma unroll
-                for (u32 u = 0; u < RCX_BWT_WALKS; ++u) {
-                    if (i < left[u]) {
-                        const u8 c = col[r[u]];
-                        for (u32 p = at[u] + i; p < RCX_BWT_BLOCK; p += cycle) stage[oshift + p] = c;
-                        r[u] = next[r[u]];
-                    }
+            const u32 there = link[v];
+            if (have && (v == first || (there >> 16) == first)) {
+                const u32 at = (v == first ? 0u : cycle - (there & 0xFFFFu)) + skip;
+                u32 n = (u32)lens[v] - skip;
+                n = n < 32u ? n : 32u;
+                u32 row = from;
+                for (u32 i = 0; i < n; ++i) {
+                    const u8 c = col[row];
+                    for (u32 p = at + i; p < RCX_BWT_BLOCK; p += cycle) stage[oshift + p] = c;
+                    row = next[row];
                 }
             }
         }
