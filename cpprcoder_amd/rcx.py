@@ -51,6 +51,15 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `python -m cpprcoder_amd.build` "
                               "(there is no CPU fallback for the HIP path)")
+        # One HIP runtime per process: PyTorch's wheel carries its own libamdhip64, librcx.so asks for the same soname.
+        # Whichever is loaded first serves both -- but if librcx.so comes first (the system's copy) and torch later
+        # brings its own, the process has two runtimes and rcx_ctx_create fails with RCX_E_HIP.  So where torch is
+        # installed it is imported first.  (A C/C++ caller without torch has only the system runtime: nothing to do.)
+        if not os.environ.get("RCX_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
         L.rcx_version.restype = i32
