@@ -77,6 +77,9 @@ __device__ __forceinline__ u32 rcx_bwt_tid()
     asm volatile("" : "+v"(t));
     return t;
 }
+// A value every lane holds alike (read from LDS, so in a vector register): moved to a scalar register, where it costs
+// no vector register and branches on it are scalar branches.
+__device__ __forceinline__ u32 rcx_bwt_same(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 
 // ---------------------------------------------------------------------------
 // global <-> LDS copies of one block.  The LDS image starts at lds + (address & 15), so that both sides of the 16-byte
@@ -330,8 +333,8 @@ __device__ __forceinline__ u32 rcx_bwt_rerank(const uint16_t* sa, uint16_t* rk, 
         rk[s[i]] = (uint16_t)((m ? k0 + 31u - (u32)__clz(m) : carry) | (((alone >> i) & 1u) ? RCX_BWT_FINAL : 0u));
     }
     __syncthreads();
-    open = left;
-    return groups;
+    open = rcx_bwt_same(left);
+    return rcx_bwt_same(groups);
 }
 
 // The rotations SA[k] - h that are not final, in the order of k, into lst[0 .. count); lst is padded with 0xFFFF up to
@@ -354,7 +357,7 @@ __device__ __forceinline__ u32 rcx_bwt_collect(const uint16_t* sa, const uint16_
     for (u32 i = 0; i < 32; ++i)
         if ((pick >> i) & 1u) lst[at + (u32)__popc(pick & ((1u << i) - 1u))] = (uint16_t)s[i];
     __syncthreads();
-    const u32 count = misc[20];
+    const u32 count = rcx_bwt_same(misc[20]);
     for (u32 p = count + tid; p < padded; p += RCX_BWT_THREADS) lst[p] = 0xFFFFu;
     __syncthreads();
     return count;
@@ -415,8 +418,8 @@ __device__ __forceinline__ u32 rcx_bwt_place(uint16_t* sa, uint16_t* rk, const u
         }
     }
     __syncthreads();
-    splits = sums & 0xFFFFu;
-    return sums >> 16;
+    splits = rcx_bwt_same(sums & 0xFFFFu);
+    return rcx_bwt_same(sums >> 16);
 }
 
 // The grid is one workgroup per CU; each takes the next block off a counter until none is left (a workgroup's 158 KiB
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
     for (;;) {
         if (tid == 0) misc[49] = atomicAdd(&ties[1], 1u);
         __syncthreads();
-        const u64 b = misc[49];
+        const u64 b = rcx_bwt_same(misc[49]);
         if (b >= nblocks) break;
         const u8* in = src + b * RCX_BWT_BLOCK;
         u8* out = dst + b * RCX_BWT_ENCODED;
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(1024) void rcx_bwt_inv_k(const u8* __restrict__ src
     for (;;) {
         if (tid == 0) misc[49] = atomicAdd(work, 1u);
         __syncthreads();
-        const u64 b = misc[49];
+        const u64 b = rcx_bwt_same(misc[49]);
         if (b >= nblocks) break;
         const u8* in = src + b * RCX_BWT_ENCODED;
         u8* out = dst + b * RCX_BWT_BLOCK;
@@ -619,12 +622,12 @@ __global__ __launch_bounds__(1024) void rcx_bwt_inv_k(const u8* __restrict__ src
         }
         __syncthreads();
         rcx_bwt_pass<32>(next, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)col[e]; });
-        u32 top = (u32)col[RCX_BWT_BLOCK] | ((u32)col[RCX_BWT_BLOCK + 1] << 8);
+        u32 top = rcx_bwt_same((u32)col[RCX_BWT_BLOCK] | ((u32)col[RCX_BWT_BLOCK + 1] << 8));
         if (top >= RCX_BWT_BLOCK) { // the reference would read outside its arrays (blksort.h:663)
             if (tid == 0) rcx_flag(status, RCX_ST_CORRUPT, b);
             top &= RCX_BWT_MASK;
         }
-        const u32 x0 = next[top];
+        const u32 x0 = rcx_bwt_same(next[top]);
         // piece v starts at row residue + 32 v and is walked by thread v; every 32nd row on the way is noted, so that
         // the second walk can be dealt out in stretches of 32 whatever the pieces' lengths are
         const u32 residue = x0 & 31u, first = x0 >> 5;
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(1024) void rcx_bwt_inv_k(const u8* __restrict__ src
         }
         if (tid == first) misc[41] = steps + ((r >> 5) == first ? 0u : link[r >> 5] & 0xFFFFu); // the length of the whole walk's cycle
         __syncthreads();
-        const u32 cycle = misc[41], marks = misc[40];
+        const u32 cycle = rcx_bwt_same(misc[41]), marks = rcx_bwt_same(misc[40]);
         u8* stage = lds + RCX_BWT_INV_OUT;
         const u32 oshift = (u32)(reinterpret_cast<uintptr_t>(out) & 15u);
         // second walk: the head of the thread's own piece, and one noted stretch
