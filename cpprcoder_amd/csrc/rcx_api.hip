@@ -55,6 +55,7 @@ struct rcx_ctx {
     u32* ties = nullptr;        // block sort: [count, (block, period) ...] of the periodic blocks of the last forward call
     u64 ties_count = 0;
     bool bwt_lds_set = false;   // the block-sort kernels have been allowed their dynamic LDS
+    bool bwt_atomic = false;    // their counting passes rank with ds_add_rtn_u32 (checked on this device) instead of ballots
     DivEntry* divtab = nullptr;
     u32 divtab_block = 0;
     u32* status = nullptr;      // device: [flags, first bad block, track0, track1]
@@ -1055,9 +1056,30 @@ int rcx_bwt_reserve(rcx_ctx* c, uint64_t n)
     if (!c) return RCX_E_ARG;
     HIP_TRY(hipSetDevice(c->device));
     if (!c->bwt_lds_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcx_bwt_fwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCX_BWT_FWD_LDS));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcx_bwt_inv_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCX_BWT_INV_LDS));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcx_bwt_fwd_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCX_BWT_FWD_LDS));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcx_bwt_fwd_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCX_BWT_FWD_LDS));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcx_bwt_inv_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCX_BWT_INV_LDS));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcx_bwt_inv_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCX_BWT_INV_LDS));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcx_bwt_tie_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCX_BWT_TIE_LDS));
+        // The counting passes may rank with one LDS atomic per key if -- and only if -- this device returns the results
+        // of one ds_add_rtn_u32 in lane order (rcx_bwt.hpp): checked here, once per context.  RCX_BWT_MATCH=ballot|atomic
+        // overrides (tests run both).
+        const char* want = getenv("RCX_BWT_MATCH");
+        if (want && !strcmp(want, "ballot")) {
+            c->bwt_atomic = false;
+        } else if (want && !strcmp(want, "atomic")) {
+            c->bwt_atomic = true;
+        } else {
+            u32 bad = 1;
+            u64 room = c->ties_count * sizeof(u32);
+            const int rr = grow(reinterpret_cast<void**>(&c->ties), &room, 8 * sizeof(u32));
+            if (rr != RCX_OK) return rr;
+            c->ties_count = room / sizeof(u32);
+            HIP_TRY(hipMemset(c->ties, 0, sizeof(u32)));
+            hipLaunchKernelGGL(rcx_bwt_lds_order_k, dim3(8), dim3(1024), 0, nullptr, 4096u, c->ties);
+            HIP_TRY(hipMemcpy(&bad, c->ties, sizeof(u32), hipMemcpyDeviceToHost));
+            c->bwt_atomic = bad == 0;
+        }
         c->bwt_lds_set = true;
     }
     const u64 blocks = n / RCX_BWT_BLOCK;
@@ -1082,7 +1104,8 @@ int rcx_bwt_encode_device(rcx_ctx* c, const void* d_src, uint64_t n, void* d_dst
     if (blocks) {
         Timed t(c, s, RCX_T_BWT_FORWARD);
         const u32 grid = (u32)(blocks < (u64)c->cus ? blocks : (u64)c->cus); // one workgroup per CU, blocks off a counter
-        hipLaunchKernelGGL(rcx_bwt_fwd_k, dim3(grid), dim3(RCX_BWT_THREADS), RCX_BWT_FWD_LDS, s, src, blocks, dst, c->ties, c->status);
+        if (c->bwt_atomic) hipLaunchKernelGGL(rcx_bwt_fwd_k<true>, dim3(grid), dim3(RCX_BWT_THREADS), RCX_BWT_FWD_LDS, s, src, blocks, dst, c->ties, c->status);
+        else hipLaunchKernelGGL(rcx_bwt_fwd_k<false>, dim3(grid), dim3(RCX_BWT_THREADS), RCX_BWT_FWD_LDS, s, src, blocks, dst, c->ties, c->status);
         // periodic blocks (rotations that tie) get the row index the reference's sort would leave; usually none
         const u64 most = 2ull * (u64)c->cus;
         hipLaunchKernelGGL(rcx_bwt_tie_k, dim3((u32)(blocks < most ? blocks : most)), dim3(64), RCX_BWT_TIE_LDS, s, src, dst,
@@ -1108,7 +1131,8 @@ int rcx_bwt_decode_device(rcx_ctx* c, const void* d_src, uint64_t n, void* d_dst
     if (blocks) {
         Timed t(c, s, RCX_T_BWT_INVERSE);
         const u32 grid = (u32)(blocks < (u64)c->cus ? blocks : (u64)c->cus);
-        hipLaunchKernelGGL(rcx_bwt_inv_k, dim3(grid), dim3(RCX_BWT_THREADS), RCX_BWT_INV_LDS, s, src, blocks, dst, c->ties + 2, c->status);
+        if (c->bwt_atomic) hipLaunchKernelGGL(rcx_bwt_inv_k<true>, dim3(grid), dim3(RCX_BWT_THREADS), RCX_BWT_INV_LDS, s, src, blocks, dst, c->ties + 2, c->status);
+        else hipLaunchKernelGGL(rcx_bwt_inv_k<false>, dim3(grid), dim3(RCX_BWT_THREADS), RCX_BWT_INV_LDS, s, src, blocks, dst, c->ties + 2, c->status);
     }
     const u64 rest = n - blocks * RCX_BWT_ENCODED;
     if (rest) HIP_TRY(hipMemcpyAsync(dst + blocks * RCX_BWT_BLOCK, src + blocks * RCX_BWT_ENCODED, rest, hipMemcpyDeviceToDevice, s));

@@ -179,16 +179,33 @@ __device__ __forceinline__ u32 rcx_bwt_block_excl(u32 v, u32* misc)
 // One stable counting pass over arr[0 .. 1024 ITERS): the elements end up ordered by their digit, equal digits in the
 // order they were in.  ELEM(x) turns what is read from arr into the element that is stored back, DIGIT(e) is its
 // digit.  Both run on whole batches of ITERS per lane before anything is counted, so their LDS reads overlap.
-template <u32 ITERS, class Elem, class Digit>
+//
+// Counting a batch of 64 keys has two forms.  The lane match above: ~60 vector instructions whatever the digits are.
+// Or ONE ds_add_rtn_u32 on the digit's count (two 16-bit counts to a dword): the value a lane gets back is the count
+// of earlier keys INCLUDING the lanes below it in this batch -- if the LDS hands the lanes of one instruction their
+// results in ascending lane order.  The ISA manual does not promise that: rcx_bwt_lds_order_k checks it on the
+// device (tools/diag/lds_order.hip is the long form: 2^33 lane-instructions without a disagreement on the MI355X),
+// and with ATOMIC = false only the match is compiled.  The atomic is fast when the 64 digits differ and slow when they
+// pile up (lanes adding to one word are served one after the other, and the LDS is the whole CU's): so every eighth
+// batch is matched, and if no digit had more than RCX_BWT_PILE lanes there the next seven use the atomic.
+// Measured, 1 GiB forward, match only / atomic only / this: uniform 13.2 / 10.5 / 9.5 ms, Zipf 13.6 / 13.1 / 11.0,
+// Canterbury 30.7 / 38.9 / 28.4, runs 77.4 / 123.7 / 78.5; thresholds of 24, 32 and 48 lanes measure the same, 6 and 12
+// worse (text: 30.2, 29.0): it takes most of the wave on one word to make the atomic the slower of the two.
+#if !defined(RCX_BWT_PILE)
+#define RCX_BWT_PILE 32u
+#endif
+// (the counts are read and written as u16 by the match and added to as dwords by the atomic: both through types that
+// may alias anything, so the compiler keeps the accesses in program order)
+typedef uint16_t __attribute__((may_alias)) RcxCount16;
+typedef u32 __attribute__((may_alias)) RcxCount32;
+template <u32 ITERS, bool ATOMIC, class Elem, class Digit>
 __device__ __forceinline__ void rcx_bwt_pass(uint16_t* arr, uint16_t* cnt, u32* misc, Elem elem, Digit digit)
 {
     const u32 tid = rcx_bwt_tid(), lane = tid & 63u, w = tid >> 6;
-    uint16_t* mine = cnt + 256u * w;
-    // (u16 stores: a dword store through another pointer type may legally be moved behind the u16 reads below)
-    mine[lane] = 0;
-    mine[lane + 64] = 0;
-    mine[lane + 128] = 0;
-    mine[lane + 192] = 0;
+    RcxCount16* mine = reinterpret_cast<RcxCount16*>(cnt + 256u * w);
+    RcxCount32* mine32 = reinterpret_cast<RcxCount32*>(cnt + 256u * w);
+    mine32[lane] = 0;
+    mine32[lane + 64] = 0;
     u32 held[ITERS]; // element | rank among the wave's earlier keys with the same digit << 16
     u32 digits[(ITERS + 3) / 4];
     const uint16_t* in = arr + 64u * ITERS * w + lane;
@@ -205,15 +222,40 @@ __device__ __forceinline__ void rcx_bwt_pass(uint16_t* arr, uint16_t* cnt, u32* 
 #pragma unroll
         for (u32 it = 0; it < ITERS; ++it) digits[it >> 2] |= dg[it] << (8u * (it & 3u));
     }
-#pragma unroll
-    for (u32 it = 0; it < ITERS; ++it) {
-        const u32 d = (digits[it >> 2] >> (8u * (it & 3u))) & 0xFFu;
-        u32 below, total;
-        rcx_bwt_match8(d, below, total);
-        const u32 old = mine[d];
-        if (below + 1 == total) mine[d] = (uint16_t)(old + total); // the highest of the peers
-        held[it] |= (old + below) << 16;
+#define RCX_BWT_COUNT_MATCHED(IT, PILED)                                                                                 \
+    {                                                                                                                  \
+        const u32 d_ = (digits[(IT) >> 2] >> (8u * ((IT) & 3u))) & 0xFFu;                                               \
+        u32 below_, total_;                                                                                            \
+        rcx_bwt_match8(d_, below_, total_);                                                                            \
+        const u32 old_ = mine[d_];                                                                                     \
+        if (below_ + 1 == total_) mine[d_] = (uint16_t)(old_ + total_); /* the highest of the peers */                 \
+        held[IT] |= (old_ + below_) << 16;                                                                             \
+        if (ATOMIC) PILED = __builtin_amdgcn_ballot_w64(total_ > RCX_BWT_PILE) != 0;                                   \
     }
+#define RCX_BWT_COUNT_ATOMIC(IT)                                                                                         \
+    {                                                                                                                  \
+        const u32 d_ = (digits[(IT) >> 2] >> (8u * ((IT) & 3u))) & 0xFFu, half_ = 16u * (d_ & 1u);                      \
+        const u32 old_ = __hip_atomic_fetch_add(&mine32[d_ >> 1], 1u << half_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); \
+        held[IT] |= (old_ >> half_) << 16; /* (<< 16 drops the neighbour digit's count when this one is the lower half) */ \
+    }
+#pragma unroll
+    for (u32 first = 0; first < ITERS; first += 8) {
+        bool piled = true;
+        RCX_BWT_COUNT_MATCHED(first, piled);
+        if (!ATOMIC || piled) {
+#pragma unroll
+            for (u32 it = first + 1; it < ITERS && it < first + 8; ++it) {
+                bool unused = true;
+                RCX_BWT_COUNT_MATCHED(it, unused);
+                (void)unused;
+            }
+        } else {
+#pragma unroll
+            for (u32 it = first + 1; it < ITERS && it < first + 8; ++it) RCX_BWT_COUNT_ATOMIC(it);
+        }
+    }
+#undef RCX_BWT_COUNT_MATCHED
+#undef RCX_BWT_COUNT_ATOMIC
     __syncthreads();
     { // 4096 counts -> their exclusive prefix in (digit, wave) order
         const u32 d = tid >> 2, w0 = 4u * (tid & 3u);
@@ -422,11 +464,53 @@ __device__ __forceinline__ u32 rcx_bwt_place(uint16_t* sa, uint16_t* rk, const u
     return rcx_bwt_same(sums >> 16);
 }
 
+// Does this device's LDS hand the lanes of one ds_add_rtn_u32 their results in ascending lane order?  16 waves run digit
+// patterns of several kinds (all values, few values, one value, two digits of one dword, neighbours colliding, one
+// bank) through the ballot match and through the atomic, as the counting pass would; *bad counts the disagreements.
+__global__ __launch_bounds__(1024) void rcx_bwt_lds_order_k(u32 rounds, u32* bad)
+{
+    __shared__ u32 tab[16][128];
+    __shared__ uint16_t ref[16][256];
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    u32 wrong = 0;
+    for (u32 r = 0; r < rounds; ++r) {
+        if ((r & 511u) == 0) { // (the 16-bit counts must not run over)
+            for (u32 i = lane; i < 128; i += 64) tab[w][i] = 0;
+            for (u32 i = lane; i < 256; i += 64) ref[w][i] = 0;
+        }
+        u32 h = r * 0x9E3779B9u + w * 131u + lane * 0x85EBCA6Bu + blockIdx.x * 977u;
+        h ^= h >> 16;
+        h *= 0x7FEB352Du;
+        h ^= h >> 15;
+        h *= 0x846CA68Bu;
+        h ^= h >> 16;
+        u32 d;
+        switch (r % 7u) {
+        case 0: d = h & 0xFFu; break;
+        case 1: d = h & 3u; break;
+        case 2: d = 7u; break;
+        case 3: d = (h & 1u) ? 201u : 200u; break;
+        case 4: d = (lane >> 2) + ((h >> 9) & 1u) * 128u; break;
+        case 5: d = (h % 4u) * 64u; break;
+        default: d = ((h >> 3) & 0x7Fu) | ((r & 1u) << 7); break;
+        }
+        u32 below, total;
+        rcx_bwt_match8(d, below, total);
+        const u32 before = ref[w][d];
+        if (below + 1 == total) ref[w][d] = (uint16_t)(before + total);
+        const u32 half = 16u * (d & 1u);
+        const u32 old = __hip_atomic_fetch_add(&tab[w][d >> 1], 1u << half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        wrong += ((old >> half) & 0xFFFFu) != before + below ? 1u : 0u;
+    }
+    if (wrong) atomicAdd(bad, wrong);
+}
+
 // The grid is one workgroup per CU; each takes the next block off a counter until none is left (a workgroup's 158 KiB
 // of LDS would otherwise be handed out again for every block: measured 9 us a block).
 // ties: [0] = count of periodic blocks with a period above 1, [1] = the forward kernel's block counter, [2] = the
 // inverse kernel's, [3] unused, then the (block, period) pairs
 #define RCX_BWT_TIES_HEAD 4u
+template <bool ATOMIC>
 __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src, u64 nblocks, u8* __restrict__ dst, u32* __restrict__ ties, u32* status)
 {
     extern __shared__ __attribute__((aligned(16))) u8 rcx_bwt_lds[];
@@ -460,11 +544,11 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
 #endif
 #pragma nounroll
         for (u32 second = 1; second < 2; --second)
-            rcx_bwt_pass<32>(sa, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)text[shift + ((e + second) & RCX_BWT_MASK)]; });
+            rcx_bwt_pass<32, ATOMIC>(sa, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)text[shift + ((e + second) & RCX_BWT_MASK)]; });
 #if defined(RCX_BWT_PROBE_PASSES) /* diagnostic build: a stable pass by the same digit again changes nothing, it only costs its time */
 #pragma nounroll
         for (u32 again = 0; again < RCX_BWT_PROBE_PASSES; ++again)
-            rcx_bwt_pass<32>(sa, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)text[shift + (e & RCX_BWT_MASK)]; });
+            rcx_bwt_pass<32, ATOMIC>(sa, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)text[shift + (e & RCX_BWT_MASK)]; });
 #endif
 #if defined(RCX_BWT_PROBE_NO_SORT)
         groups = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return ((u32)text[shift + s] << 8) | text[shift + ((s + 1u) & RCX_BWT_MASK)]; }, open);
@@ -478,7 +562,7 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
 #pragma nounroll
                 for (u32 high = 0; high < 2; ++high) {
                     const u32 back = high ? 0u : h, down = 8u * high;
-                    rcx_bwt_pass<32>(sa, cnt, misc, [&](u32 x) { return (x - back) & RCX_BWT_MASK; },
+                    rcx_bwt_pass<32, ATOMIC>(sa, cnt, misc, [&](u32 x) { return (x - back) & RCX_BWT_MASK; },
                                      [&](u32 e) { return (((u32)rk[e] & RCX_BWT_MASK) >> down) & 0xFFu; });
                 }
                 const u32 now = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return (((u32)rk[s] & RCX_BWT_MASK) << 16) | ((u32)rk[(s + h) & RCX_BWT_MASK] & RCX_BWT_MASK); }, open);
@@ -493,12 +577,12 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
                 if (big) {
 #pragma nounroll
                     for (u32 down = 0; down < 16; down += 8)
-                        rcx_bwt_pass<RCX_BWT_LIST_BIG>(lst, cnt, misc, same, [&](u32 e) { return e == 0xFFFFu ? 0xFFu : (((u32)rk[e & RCX_BWT_MASK] & RCX_BWT_MASK) >> down) & 0xFFu; });
+                        rcx_bwt_pass<RCX_BWT_LIST_BIG, ATOMIC>(lst, cnt, misc, same, [&](u32 e) { return e == 0xFFFFu ? 0xFFu : (((u32)rk[e & RCX_BWT_MASK] & RCX_BWT_MASK) >> down) & 0xFFu; });
                     open = rcx_bwt_place<RCX_BWT_LIST_BIG>(sa, rk, lst, misc, h, count, splits);
                 } else {
 #pragma nounroll
                     for (u32 down = 0; down < 16; down += 8)
-                        rcx_bwt_pass<RCX_BWT_LIST_SMALL>(lst, cnt, misc, same, [&](u32 e) { return e == 0xFFFFu ? 0xFFu : (((u32)rk[e & RCX_BWT_MASK] & RCX_BWT_MASK) >> down) & 0xFFu; });
+                        rcx_bwt_pass<RCX_BWT_LIST_SMALL, ATOMIC>(lst, cnt, misc, same, [&](u32 e) { return e == 0xFFFFu ? 0xFFu : (((u32)rk[e & RCX_BWT_MASK] & RCX_BWT_MASK) >> down) & 0xFFu; });
                     open = rcx_bwt_place<RCX_BWT_LIST_SMALL>(sa, rk, lst, misc, h, count, splits);
                 }
                 if (splits == 0) break; // periodic (cannot happen with a list this short, but it is the same test)
@@ -591,6 +675,7 @@ __global__ __launch_bounds__(64) void rcx_bwt_tie_k(const u8* __restrict__ src, 
 // / 4 walks: uniform 7.90 / 8.64 / 8.38 ms, Canterbury 10.7 / 13.3 / 15.2 ms).  `next` is a permutation whatever the input, so every walk ends;
 // if the walk from next[top] closes after C < 32768 steps (a periodic block, or garbage) the reference keeps going
 // round, and so do the writes here (position + m C).
+template <bool ATOMIC>
 __global__ __launch_bounds__(1024) void rcx_bwt_inv_k(const u8* __restrict__ src, u64 nblocks, u8* __restrict__ dst, u32* __restrict__ work, u32* status)
 {
     extern __shared__ __attribute__((aligned(16))) u8 rcx_bwt_lds[];
@@ -621,7 +706,7 @@ __global__ __launch_bounds__(1024) void rcx_bwt_inv_k(const u8* __restrict__ src
             for (u32 i = 0; i < 32; ++i) next[k0 + i] = (uint16_t)(k0 + i);
         }
         __syncthreads();
-        rcx_bwt_pass<32>(next, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)col[e]; });
+        rcx_bwt_pass<32, ATOMIC>(next, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)col[e]; });
         u32 top = rcx_bwt_same((u32)col[RCX_BWT_BLOCK] | ((u32)col[RCX_BWT_BLOCK + 1] << 8));
         if (top >= RCX_BWT_BLOCK) { // the reference would read outside its arrays (blksort.h:663)
             if (tid == 0) rcx_flag(status, RCX_ST_CORRUPT, b);
