@@ -1070,15 +1070,21 @@ int rcx_bwt_reserve(rcx_ctx* c, uint64_t n)
         } else if (want && !strcmp(want, "atomic")) {
             c->bwt_atomic = true;
         } else {
-            u32 bad = 1;
-            u64 room = c->ties_count * sizeof(u32);
-            const int rr = grow(reinterpret_cast<void**>(&c->ties), &room, 8 * sizeof(u32));
-            if (rr != RCX_OK) return rr;
-            c->ties_count = room / sizeof(u32);
-            HIP_TRY(hipMemset(c->ties, 0, sizeof(u32)));
-            hipLaunchKernelGGL(rcx_bwt_lds_order_k, dim3(8), dim3(1024), 0, nullptr, 4096u, c->ties);
-            HIP_TRY(hipMemcpy(&bad, c->ties, sizeof(u32), hipMemcpyDeviceToHost));
-            c->bwt_atomic = bad == 0;
+            // (one answer per device and process: 0.3 ms the first time; a benign race if two threads ask at once)
+            static int known[64]; // 0 = not asked, 1 = lane order holds, 2 = it does not
+            int& answer = known[c->device & 63];
+            if (answer == 0) {
+                u32 bad = 1;
+                u64 room = c->ties_count * sizeof(u32);
+                const int rr = grow(reinterpret_cast<void**>(&c->ties), &room, 8 * sizeof(u32));
+                if (rr != RCX_OK) return rr;
+                c->ties_count = room / sizeof(u32);
+                HIP_TRY(hipMemset(c->ties, 0, sizeof(u32)));
+                hipLaunchKernelGGL(rcx_bwt_lds_order_k, dim3(4), dim3(1024), 0, nullptr, 512u, c->ties);
+                HIP_TRY(hipMemcpy(&bad, c->ties, sizeof(u32), hipMemcpyDeviceToHost));
+                answer = bad == 0 ? 1 : 2;
+            }
+            c->bwt_atomic = answer == 1;
         }
         c->bwt_lds_set = true;
     }
