@@ -328,17 +328,19 @@ __device__ __forceinline__ u32 rcx_bwt_block_sum(u32 v, u32* misc)
     return all;
 }
 
-// New groups: row k starts one if KEY(SA[k]) differs from KEY(SA[k - 1]); RK[SA[k]] = the first row of k's group, with
-// RCX_BWT_FINAL if the group is that one row.  Thread t looks at rows [32 t, 32 t + 32).  Returns the number of groups,
-// `open` = the rotations that are not final.  misc: 48 dwords.
+// New groups: row k starts one if it did already (a sort moves rotations inside their groups only, so the rows where
+// groups start stay: `starts` / `behind` are this thread's 32 bits of that and the bit of the row behind them, kept in
+// registers from one round to the next) or if KEY(SA[k]) differs from KEY(SA[k - 1]).  RK[SA[k]] = the first row of k's
+// group, with RCX_BWT_FINAL if the group is that one row.  Thread t looks at rows [32 t, 32 t + 32).  Returns the
+// number of groups, `open` = the rotations that are not final.  misc: 48 dwords.
 template <class Key>
-__device__ __forceinline__ u32 rcx_bwt_rerank(const uint16_t* sa, uint16_t* rk, u32* misc, Key key, u32& open)
+__device__ __forceinline__ u32 rcx_bwt_rerank(const uint16_t* sa, uint16_t* rk, u32* misc, Key key, u32& open, u32& starts, u32& behind)
 {
     const u32 tid = rcx_bwt_tid(), lane = tid & 63u, w = tid >> 6, k0 = 32u * tid;
     u32 s[32];
     rcx_bwt_rows32(sa, k0, s);
     u32 prev = key((u32)sa[(k0 + RCX_BWT_MASK) & RCX_BWT_MASK]);
-    u32 bits = 0;
+    u32 bits = starts;
 #pragma unroll
     for (u32 i = 0; i < 32; ++i) {
         const u32 kk = key(s[i]);
@@ -347,7 +349,8 @@ __device__ __forceinline__ u32 rcx_bwt_rerank(const uint16_t* sa, uint16_t* rk, 
     }
     if (tid == 0) bits |= 1u;
     // does the row behind this thread's start a group?  (behind the last row: yes)
-    const u32 behind = (tid == RCX_BWT_THREADS - 1u || key((u32)sa[(k0 + 32u) & RCX_BWT_MASK]) != prev) ? 1u : 0u;
+    behind |= (tid == RCX_BWT_THREADS - 1u || key((u32)sa[(k0 + 32u) & RCX_BWT_MASK]) != prev) ? 1u : 0u;
+    starts = bits;
     const u32 alone = bits & ((bits >> 1) | (behind << 31));
     // the last group start at or before each row: inside the thread from `bits`, before it a running maximum
     const u32 last = bits ? k0 + 31u - (u32)__clz(bits) : 0u;
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
         }
         __syncthreads();
 #if defined(RCX_BWT_PROBE_NO_SORT) /* diagnostic build: what everything around the sort costs (the output is NOT the transform) */
-        u32 open = 0, groups = RCX_BWT_BLOCK;
+        u32 open = 0, groups = RCX_BWT_BLOCK, starts = 0, behind = 0;
         if (src == nullptr) {
 #endif
 #pragma nounroll
@@ -551,11 +554,11 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
             rcx_bwt_pass<32, ATOMIC>(sa, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)text[shift + (e & RCX_BWT_MASK)]; });
 #endif
 #if defined(RCX_BWT_PROBE_NO_SORT)
-        groups = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return ((u32)text[shift + s] << 8) | text[shift + ((s + 1u) & RCX_BWT_MASK)]; }, open);
+        groups = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return ((u32)text[shift + s] << 8) | text[shift + ((s + 1u) & RCX_BWT_MASK)]; }, open, starts, behind);
         }
 #else
-        u32 open;
-        u32 groups = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return ((u32)text[shift + s] << 8) | text[shift + ((s + 1u) & RCX_BWT_MASK)]; }, open);
+        u32 open, starts = 0, behind = 0;
+        u32 groups = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return ((u32)text[shift + s] << 8) | text[shift + ((s + 1u) & RCX_BWT_MASK)]; }, open, starts, behind);
 #endif
         for (u32 h = 2; open > 0 && h < RCX_BWT_BLOCK; h <<= 1) {
             if (open > 1024u * RCX_BWT_LIST_BIG) {
@@ -565,7 +568,8 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
                     rcx_bwt_pass<32, ATOMIC>(sa, cnt, misc, [&](u32 x) { return (x - back) & RCX_BWT_MASK; },
                                      [&](u32 e) { return (((u32)rk[e] & RCX_BWT_MASK) >> down) & 0xFFu; });
                 }
-                const u32 now = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return (((u32)rk[s] & RCX_BWT_MASK) << 16) | ((u32)rk[(s + h) & RCX_BWT_MASK] & RCX_BWT_MASK); }, open);
+                // (inside a group of the h-order only the second h bytes can tell two rotations apart)
+                const u32 now = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return (u32)rk[(s + h) & RCX_BWT_MASK] & RCX_BWT_MASK; }, open, starts, behind);
                 if (now == groups) break; // nothing split: the block is periodic, `groups` is its period
                 groups = now;
             } else {
@@ -592,7 +596,7 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
 #if defined(RCX_BWT_PROBE_RERANKS) /* diagnostic build, data whose rows are all final by now: the same ranks again, for their time */
 #pragma nounroll
         for (u32 again = 0; again < RCX_BWT_PROBE_RERANKS; ++again)
-            (void)rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return (((u32)rk[s] & RCX_BWT_MASK) << 16) | ((u32)rk[(s + 2u) & RCX_BWT_MASK] & RCX_BWT_MASK); }, open);
+            (void)rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return (u32)rk[(s + 2u) & RCX_BWT_MASK] & RCX_BWT_MASK; }, open, starts, behind);
 #endif
         // the last column (blksort.h:511-518): byte in front of every row's rotation
         u32 s[32];
