@@ -1008,6 +1008,15 @@ int rcx_debug_dec_stamps(unsigned long long* out8)
     return hipMemcpyFromSymbol(out8, HIP_SYMBOL(rcx_dec_stamp_out), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif
+#if defined(RCX_BWT_STAMP)
+int rcx_debug_bwt_stamps(unsigned long long* out16, int reset)
+{
+    static const unsigned long long zero[16] = {};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rcx_bwt_stamp_out), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(rcx_bwt_stamp_out), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 #if defined(RCX_STAMP)
 int rcx_debug_stamps(unsigned long long* out16)
 {

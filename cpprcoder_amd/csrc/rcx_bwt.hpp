@@ -513,6 +513,17 @@ __global__ __launch_bounds__(1024) void rcx_bwt_lds_order_k(u32 rounds, u32* bad
 // ties: [0] = count of periodic blocks with a period above 1, [1] = the forward kernel's block counter, [2] = the
 // inverse kernel's, [3] unused, then the (block, period) pairs
 #define RCX_BWT_TIES_HEAD 4u
+#if defined(RCX_BWT_STAMP) /* diagnostic build only (tools/diag/stamp_bwt.py): cycles per phase, summed over blocks by thread 0 of each workgroup */
+static __device__ unsigned long long rcx_bwt_stamp_out[16];
+#define RCX_BWT_PHASE(i)                                                         \
+    {                                                                            \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();            \
+        stamp_[i] += now_ - mark_;                                               \
+        mark_ = now_;                                                            \
+    }
+#else
+#define RCX_BWT_PHASE(i)
+#endif
 template <bool ATOMIC>
 __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src, u64 nblocks, u8* __restrict__ dst, u32* __restrict__ ties, u32* status)
 {
@@ -524,7 +535,11 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
     u32* misc = reinterpret_cast<u32*>(lds + RCX_BWT_FWD_MISC);
     uint16_t* lst = reinterpret_cast<uint16_t*>(lds + RCX_BWT_FWD_LIST);
     const u32 tid = threadIdx.x;
+#if defined(RCX_BWT_STAMP)
+    unsigned long long stamp_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mark_ = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
+        RCX_BWT_PHASE(11) // between blocks
         if (tid == 0) misc[49] = atomicAdd(&ties[1], 1u);
         __syncthreads();
         const u64 b = rcx_bwt_same(misc[49]);
@@ -534,6 +549,7 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
         u8* text = lds + RCX_BWT_FWD_RK;
         const u32 shift = rcx_bwt_stage_in(text, in, RCX_BWT_BLOCK);
         __syncthreads();
+        RCX_BWT_PHASE(0) // block in
         // rows by their first two bytes: the second byte first (rows in index order), then the first
         {
             const u32 k0 = 32u * rcx_bwt_tid();
@@ -557,8 +573,10 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
         groups = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return ((u32)text[shift + s] << 8) | text[shift + ((s + 1u) & RCX_BWT_MASK)]; }, open, starts, behind);
         }
 #else
+        RCX_BWT_PHASE(1) // the two passes of the start
         u32 open, starts = 0, behind = 0;
         u32 groups = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return ((u32)text[shift + s] << 8) | text[shift + ((s + 1u) & RCX_BWT_MASK)]; }, open, starts, behind);
+        RCX_BWT_PHASE(2) // regrouping
 #endif
         for (u32 h = 2; open > 0 && h < RCX_BWT_BLOCK; h <<= 1) {
             if (open > 1024u * RCX_BWT_LIST_BIG) {
@@ -568,13 +586,16 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
                     rcx_bwt_pass<32, ATOMIC>(sa, cnt, misc, [&](u32 x) { return (x - back) & RCX_BWT_MASK; },
                                      [&](u32 e) { return (((u32)rk[e] & RCX_BWT_MASK) >> down) & 0xFFu; });
                 }
+                RCX_BWT_PHASE(3) // full passes
                 // (inside a group of the h-order only the second h bytes can tell two rotations apart)
                 const u32 now = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return (u32)rk[(s + h) & RCX_BWT_MASK] & RCX_BWT_MASK; }, open, starts, behind);
+                RCX_BWT_PHASE(2)
                 if (now == groups) break; // nothing split: the block is periodic, `groups` is its period
                 groups = now;
             } else {
                 const bool big = open > 1024u * RCX_BWT_LIST_SMALL;
                 const u32 count = rcx_bwt_collect(sa, rk, lst, misc, h, 1024u * (big ? RCX_BWT_LIST_BIG : RCX_BWT_LIST_SMALL));
+                RCX_BWT_PHASE(4) // collect
                 // by group: a padding entry (0xFFFF) sorts behind everything
                 const auto same = [](u32 x) { return x; };
                 u32 splits;
@@ -582,12 +603,16 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
 #pragma nounroll
                     for (u32 down = 0; down < 16; down += 8)
                         rcx_bwt_pass<RCX_BWT_LIST_BIG, ATOMIC>(lst, cnt, misc, same, [&](u32 e) { return e == 0xFFFFu ? 0xFFu : (((u32)rk[e & RCX_BWT_MASK] & RCX_BWT_MASK) >> down) & 0xFFu; });
+                    RCX_BWT_PHASE(5) // list passes (long list)
                     open = rcx_bwt_place<RCX_BWT_LIST_BIG>(sa, rk, lst, misc, h, count, splits);
+                    RCX_BWT_PHASE(7) // place
                 } else {
 #pragma nounroll
                     for (u32 down = 0; down < 16; down += 8)
                         rcx_bwt_pass<RCX_BWT_LIST_SMALL, ATOMIC>(lst, cnt, misc, same, [&](u32 e) { return e == 0xFFFFu ? 0xFFu : (((u32)rk[e & RCX_BWT_MASK] & RCX_BWT_MASK) >> down) & 0xFFu; });
+                    RCX_BWT_PHASE(6) // list passes (short list)
                     open = rcx_bwt_place<RCX_BWT_LIST_SMALL>(sa, rk, lst, misc, h, count, splits);
+                    RCX_BWT_PHASE(7)
                 }
                 if (splits == 0) break; // periodic (cannot happen with a list this short, but it is the same test)
                 groups += splits;
@@ -598,6 +623,7 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
         for (u32 again = 0; again < RCX_BWT_PROBE_RERANKS; ++again)
             (void)rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return (u32)rk[(s + 2u) & RCX_BWT_MASK] & RCX_BWT_MASK; }, open, starts, behind);
 #endif
+        RCX_BWT_PHASE(8) // (loop ends)
         // the last column (blksort.h:511-518): byte in front of every row's rotation
         u32 s[32];
         {
@@ -633,9 +659,18 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
             }
         }
         __syncthreads();
+        RCX_BWT_PHASE(9) // column gathered
         rcx_bwt_stage_out(out, stage, RCX_BWT_ENCODED);
         __syncthreads();
+        RCX_BWT_PHASE(10) // block out
+#if defined(RCX_BWT_STAMP)
+        stamp_[8] += 0; // (slot 8 is time between the last round and the column: loop control)
+#endif
     }
+#if defined(RCX_BWT_STAMP)
+    if (tid == 0)
+        for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&rcx_bwt_stamp_out[i_], stamp_[i_]);
+#endif
 }
 
 // Periodic blocks: the row index as the reference's sort leaves it.  One wave per listed block, lane 0 replays.
