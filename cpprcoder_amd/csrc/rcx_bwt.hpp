@@ -23,14 +23,15 @@
 // same two counting passes -- a third or a tenth as long -- and lands in the open rows, which it fills exactly.
 //
 // A stable counting pass of 32768 keys by 1024 lanes: wave w owns keys [2048 w, 2048 w + 2048), 64 at a time in index
-// order; within the 64, lanes with the same digit find each other with 8 ballots, the lowest ones first; per wave and
-// digit a running count in LDS gives the rank among the wave's earlier keys; after an exclusive scan of the 16 x 256
-// counts in (digit, wave) order every key knows its place.  The keys stay in registers between the count and the
-// scatter, so one array is sorted in place.
+// order; per wave and digit a running count in LDS gives every key its rank among the wave's earlier keys with the
+// same digit -- within the 64 of a batch either by 8 ballots (lanes with the same digit find each other, the lowest
+// ones first) or by one LDS atomic per key where the device serves a wave's lanes in lane order (rcx_bwt_pass);
+// after an exclusive scan of the 16 x 256 counts in (digit, wave) order every key knows its place.  The keys stay in
+// registers between the count and the scatter, so one array is sorted in place.
 //
-// LDS (forward): SA 64 KiB | RK 64 KiB | counts 8 KiB | 256 B | list 22 KiB.  RK's space first holds the block itself (the two-byte
-// keys are bytes of it) and at the end again (the column is gathered from it); SA's space ends as the staging buffer
-// the 32770 output bytes leave from in aligned 16-byte pieces.  One workgroup per CU.
+// LDS (forward): SA 64 KiB | RK 64 KiB | counts 8 KiB | 256 B | list 22 KiB.  RK's space first holds the block itself
+// (the two-byte keys are bytes of it) and at the end again (the column is gathered from it); SA's space ends as the
+// staging buffer the 32770 output bytes leave from in aligned 16-byte pieces.  One workgroup per CU.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -120,7 +121,9 @@ __device__ __forceinline__ void rcx_bwt_match8(u32 d, u32& below, u32& total)
     for (u32 b = 0; b < 8; ++b) {
         const u32 mine = (u32)((s32)(d << (31u - b)) >> 31); // bit b of d on every bit
         u64 bal;
-        asm("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(bal) : "v"(mine)); // (as a ballot the compiler tests a second, shifted copy of d)
+        // (written out: as a ballot builtin the compiler tests a second, shifted copy of d; volatile: the result depends
+        // on which lanes are active, which the compiler does not see in the operands)
+        asm volatile("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(bal) : "v"(mine));
         lo &= ~((u32)bal ^ mine);
         hi &= ~((u32)(bal >> 32) ^ mine);
     }
@@ -157,7 +160,6 @@ __device__ __forceinline__ u32 rcx_bwt_wave_incl_max(u32 v)
 }
 // the value of the lane before (0 for lane 0): wave_shr:1
 __device__ __forceinline__ u32 rcx_bwt_wave_prev(u32 v) { return rcx_bwt_dpp0<0x138, 0xF, 0xF>(v); }
-__device__ __forceinline__ u32 rcx_bwt_wave_last(u32 v) { return (u32)__builtin_amdgcn_readlane((int)v, 63); }
 
 // exclusive prefix sum over the workgroup (all 1024 threads call it); misc: 16 dwords
 __device__ __forceinline__ u32 rcx_bwt_block_excl(u32 v, u32* misc)
