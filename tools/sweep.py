@@ -52,12 +52,24 @@ def main():
                         enc_ms.append(t["encode"]["ms"] + t["scan"]["ms"] + t["scatter"]["ms"])
                         dec_ms.append(t["decode"]["ms"])
                 ok = bool(torch.equal(out, src))
+                # launch shape of the adaptive coder (rcx_api.hip: encode_lanes / decode_quads; SURVEY.md section 8(d) config 5
+                # asks for waves per CU and LDS bytes per wave next to the rates)
+                shape = {}
+                if args.coder == 0:
+                    cus = 256
+                    pow2 = lambda x: 1 << max(0, (int(x) - 1).bit_length())
+                    lanes = min(64, pow2(-(-nblocks // cus)))
+                    quads = min(16, pow2(-(-nblocks // (4 * cus))))
+                    enc_wgs, dec_waves = -(-nblocks // lanes), -(-nblocks // quads)
+                    shape = {"enc_blocks_per_workgroup": lanes, "enc_workgroups": enc_wgs, "enc_waves_per_cu": round(5 * min(enc_wgs, cus) / cus, 2),
+                             "enc_lds_bytes_per_wave": 146432 // 5, "dec_blocks_per_wave": quads, "dec_waves": dec_waves,
+                             "dec_waves_per_cu": round(min(dec_waves, 8 * cus) / cus, 2), "dec_lds_bytes_per_wave": 79872 // 4}
                 total = int(offs[-1])
                 e, d = sorted(enc_ms)[1], sorted(dec_ms)[1]
                 line = {"coder": ("adaptive", "static", "rans", "rans8")[args.coder], "workload": wl, "bytes": n, "block": block, "blocks": nblocks, "ratio": round(total / n, 6),
                         "encode_ms": round(e, 3), "decode_ms": round(d, 3), "encode_MBps": round(n / 1e6 / (e * 1e-3), 1),
                         "decode_MBps": round(n / 1e6 / (d * 1e-3), 1), "roundtrip_MBps": round(n / 1e6 / ((e + d) * 1e-3), 1),
-                        "roundtrip_ok": ok, "gen_s": round(gen_s, 1)}
+                        "roundtrip_ok": ok, "gen_s": round(gen_s, 1), **shape}
                 print(json.dumps(line), flush=True)
                 f.write(json.dumps(line) + "\n")
                 f.flush()
