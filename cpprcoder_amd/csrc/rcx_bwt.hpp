@@ -552,34 +552,109 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
         const u32 shift = rcx_bwt_stage_in(text, in, RCX_BWT_BLOCK);
         __syncthreads();
         RCX_BWT_PHASE(0) // block in
-        // rows by their first two bytes: the second byte first (rows in index order), then the first
+        u32 open = 0, groups = RCX_BWT_BLOCK, starts = 0, behind = 0;
+        // Where does a byte differ from the next one?  If in fewer than half of the places, the block is mostly runs of
+        // one byte, which prefix doubling alone resolves one doubling per round (a run of 4000: 12 rounds): such a block
+        // starts from deeper keys instead -- (byte, how the run ends, its length, the byte behind it), rcx_bwt_run_key --
+        // which order the rotations inside a run at once.  Ranks of unequal depth are fine for the rounds as long as
+        // they agree with the true order and every one is at least h bytes deep when the round with shift h starts.
+        u32* change = reinterpret_cast<u32*>(lst);                    // 1024 dwords: bit i of dword t = byte 32 t + i differs from the next
+        uint16_t* next_change = reinterpret_cast<uint16_t*>(lst) + 2048; // 1025 entries: first such place at or behind 32 t (+ 32768 when it wraps)
+        bool by_runs = false;
+#if !defined(RCX_BWT_NO_RUN_START) && !defined(RCX_BWT_PROBE_NO_SORT) && !defined(RCX_BWT_PROBE_PASSES)
         {
             const u32 k0 = 32u * rcx_bwt_tid();
+            u32 differs = 0;
+            if (shift == 0) { // (the usual case: the block sits aligned in LDS and is read eight bytes a step)
+                const U4 lo = *reinterpret_cast<const U4*>(text + k0), hi = *reinterpret_cast<const U4*>(text + k0 + 16);
+                const u32 w[9] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, (u32)text[(k0 + 32u) & RCX_BWT_MASK]};
 #pragma unroll
-            for (u32 i = 0; i < 32; ++i) sa[k0 + i] = (uint16_t)(k0 + i);
+                for (u32 q = 0; q < 8; ++q) {
+                    const u32 x = w[q] ^ ((w[q] >> 8) | (w[q + 1] << 24)); // byte j of x: byte j against byte j + 1
+                    differs |= (((x & 0xFFu) ? 1u : 0u) | ((x & 0xFF00u) ? 2u : 0u) | ((x & 0xFF0000u) ? 4u : 0u) | ((x >> 24) ? 8u : 0u)) << (4u * q);
+                }
+            } else {
+                u32 before = text[shift + k0];
+#pragma unroll
+                for (u32 i = 0; i < 32; ++i) {
+                    const u32 here = text[shift + ((k0 + i + 1u) & RCX_BWT_MASK)];
+                    differs |= (here != before ? 1u : 0u) << i;
+                    before = here;
+                }
+            }
+            change[tid] = differs;
+            next_change[tid] = (uint16_t)(differs ? k0 + (u32)__builtin_ctz(differs) : 0xFFFFu);
+            const u32 changes = rcx_bwt_same(rcx_bwt_block_sum((u32)__popc(differs), misc));
+            by_runs = changes < RCX_BWT_BLOCK / 2;
         }
-        __syncthreads();
+#endif
+        if (by_runs) {
+            // the first change at or behind every 32nd place: a minimum over the places behind, by doubling
+            u32 mine = next_change[tid];
+#pragma nounroll
+            for (u32 step = 1; step < RCX_BWT_THREADS; step <<= 1) {
+                const u32 other = tid + step < RCX_BWT_THREADS ? (u32)next_change[tid + step] : 0xFFFFu;
+                __syncthreads();
+                mine = mine < other ? mine : other;
+                next_change[tid] = (uint16_t)mine;
+                __syncthreads();
+            }
+            const u32 first_change = rcx_bwt_same(next_change[0]); // 0xFFFF: the block is one byte over and over
+            __syncthreads();
+            if (mine == 0xFFFFu) next_change[tid] = (uint16_t)(RCX_BWT_BLOCK + first_change);
+            if (tid == 0) next_change[RCX_BWT_THREADS] = (uint16_t)(RCX_BWT_BLOCK + first_change);
+            {
+                const u32 k0 = 32u * rcx_bwt_tid();
+#pragma unroll
+                for (u32 i = 0; i < 32; ++i) sa[k0 + i] = (uint16_t)(k0 + i);
+            }
+            __syncthreads();
+            if (first_change == 0xFFFFu) {
+                groups = 1; // all rotations are equal: any order is the order, row 0 is where the reference leaves it
+                open = 0;
+            } else {
+                // (byte << 24) | (how the run ends and how long it is: 16 bits) << 8 | the byte behind the run
+                const auto run_key = [&](u32 p) {
+                    const u32 rest = change[p >> 5] >> (p & 31u);
+                    const u32 last = rest ? p + (u32)__builtin_ctz(rest) : (u32)next_change[(p >> 5) + 1u]; // the run's last place
+                    const u32 len = last - p + 1u;
+                    const u32 c = text[shift + p], b = text[shift + ((p + len) & RCX_BWT_MASK)];
+                    // a run ended by a smaller byte sorts before every longer run, shortest first; by a larger one behind, longest first
+                    return (c << 24) | ((b > c ? 65535u - len : len) << 8) | b;
+                };
+#pragma nounroll
+                for (u32 down = 0; down < 32; down += 8)
+                    rcx_bwt_pass<32, ATOMIC>(sa, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (run_key(e) >> down) & 0xFFu; });
+                RCX_BWT_PHASE(1)
+                groups = rcx_bwt_rerank(sa, rk, misc, run_key, open, starts, behind);
+                RCX_BWT_PHASE(2)
+            }
+        } else {
+            // rows by their first two bytes: the second byte first (rows in index order), then the first
+            {
+                const u32 k0 = 32u * rcx_bwt_tid();
+#pragma unroll
+                for (u32 i = 0; i < 32; ++i) sa[k0 + i] = (uint16_t)(k0 + i);
+            }
+            __syncthreads();
 #if defined(RCX_BWT_PROBE_NO_SORT) /* diagnostic build: what everything around the sort costs (the output is NOT the transform) */
-        u32 open = 0, groups = RCX_BWT_BLOCK, starts = 0, behind = 0;
-        if (src == nullptr) {
+            if (src == nullptr) {
 #endif
 #pragma nounroll
-        for (u32 second = 1; second < 2; --second)
-            rcx_bwt_pass<32, ATOMIC>(sa, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)text[shift + ((e + second) & RCX_BWT_MASK)]; });
+            for (u32 second = 1; second < 2; --second)
+                rcx_bwt_pass<32, ATOMIC>(sa, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)text[shift + ((e + second) & RCX_BWT_MASK)]; });
 #if defined(RCX_BWT_PROBE_PASSES) /* diagnostic build: a stable pass by the same digit again changes nothing, it only costs its time */
 #pragma nounroll
-        for (u32 again = 0; again < RCX_BWT_PROBE_PASSES; ++again)
-            rcx_bwt_pass<32, ATOMIC>(sa, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)text[shift + (e & RCX_BWT_MASK)]; });
+            for (u32 again = 0; again < RCX_BWT_PROBE_PASSES; ++again)
+                rcx_bwt_pass<32, ATOMIC>(sa, cnt, misc, [](u32 x) { return x; }, [&](u32 e) { return (u32)text[shift + (e & RCX_BWT_MASK)]; });
 #endif
+            RCX_BWT_PHASE(1) // the two passes of the start
+            groups = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return ((u32)text[shift + s] << 8) | text[shift + ((s + 1u) & RCX_BWT_MASK)]; }, open, starts, behind);
+            RCX_BWT_PHASE(2) // regrouping
 #if defined(RCX_BWT_PROBE_NO_SORT)
-        groups = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return ((u32)text[shift + s] << 8) | text[shift + ((s + 1u) & RCX_BWT_MASK)]; }, open, starts, behind);
-        }
-#else
-        RCX_BWT_PHASE(1) // the two passes of the start
-        u32 open, starts = 0, behind = 0;
-        u32 groups = rcx_bwt_rerank(sa, rk, misc, [&](u32 s) { return ((u32)text[shift + s] << 8) | text[shift + ((s + 1u) & RCX_BWT_MASK)]; }, open, starts, behind);
-        RCX_BWT_PHASE(2) // regrouping
+            }
 #endif
+        }
         for (u32 h = 2; open > 0 && h < RCX_BWT_BLOCK; h <<= 1) {
             if (open > 1024u * RCX_BWT_LIST_BIG) {
 #pragma nounroll
