@@ -17,6 +17,10 @@
 // block is periodic (if h bytes and 2h bytes give the same classes, so does any depth): the number of groups then is
 // the period, the column is right whatever the order inside the ties, and the row index is rcx_bwt_tie_k's.
 //
+// A block that is mostly runs of one byte starts from deeper keys than two bytes (byte, how its run ends, the run's
+// length, the byte behind the run: rcx_bwt_fwd_k), which order the rotations inside a run at once; the rounds work on
+// ranks of unequal depth as long as they agree with the true order and are at least h bytes deep at the round with shift h.
+//
 // Rounds get cheaper: a rotation that is alone in its group has its final row (RK carries a flag for it), and once the
 // rotations that are not fit a list in LDS (11264 entries; text gets there after two or three rounds) a round only
 // touches those: the SA[k] - h that are still open are collected in row order, that list is sorted by group with the
@@ -515,6 +519,10 @@ __global__ __launch_bounds__(1024) void rcx_bwt_lds_order_k(u32 rounds, u32* bad
 // ties: [0] = count of periodic blocks with a period above 1, [1] = the forward kernel's block counter, [2] = the
 // inverse kernel's, [3] unused, then the (block, period) pairs
 #define RCX_BWT_TIES_HEAD 4u
+#if !defined(RCX_BWT_RUNNY)
+#define RCX_BWT_RUNNY (RCX_BWT_BLOCK / 8) /* fewer places than this where a byte differs from the next: the block starts from run keys */
+/* (measured on the Canterbury GiB: 27.2 ms with 16384, 26.9 with 4096, 27.0 with 1024; the runs workload takes the run keys with any of them) */
+#endif
 #if defined(RCX_BWT_STAMP) /* diagnostic build only (tools/diag/stamp_bwt.py): cycles per phase, summed over blocks by thread 0 of each workgroup */
 static __device__ unsigned long long rcx_bwt_stamp_out[16];
 #define RCX_BWT_PHASE(i)                                                         \
@@ -553,7 +561,7 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
         __syncthreads();
         RCX_BWT_PHASE(0) // block in
         u32 open = 0, groups = RCX_BWT_BLOCK, starts = 0, behind = 0;
-        // Where does a byte differ from the next one?  If in fewer than half of the places, the block is mostly runs of
+        // Where does a byte differ from the next one?  If in fewer than an eighth of the places, the block is mostly runs of
         // one byte, which prefix doubling alone resolves one doubling per round (a run of 4000: 12 rounds): such a block
         // starts from deeper keys instead -- (byte, how the run ends, its length, the byte behind it), rcx_bwt_run_key --
         // which order the rotations inside a run at once.  Ranks of unequal depth are fine for the rounds as long as
@@ -585,7 +593,7 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
             change[tid] = differs;
             next_change[tid] = (uint16_t)(differs ? k0 + (u32)__builtin_ctz(differs) : 0xFFFFu);
             const u32 changes = rcx_bwt_same(rcx_bwt_block_sum((u32)__popc(differs), misc));
-            by_runs = changes < RCX_BWT_BLOCK / 2;
+            by_runs = changes < RCX_BWT_RUNNY;
         }
 #endif
         if (by_runs) {
