@@ -128,8 +128,9 @@ __device__ __forceinline__ void rcx_bwt_match8(u32 d, u32& below, u32& total)
         // (written out: as a ballot builtin the compiler tests a second, shifted copy of d; volatile: the result depends
         // on which lanes are active, which the compiler does not see in the operands)
         asm volatile("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(bal) : "v"(mine));
-        lo &= ~((u32)bal ^ mine);
-        hi &= ~((u32)(bal >> 32) ^ mine);
+        // keep & ~(ballot ^ mine) in one v_bitop3_b32 each (table 0x90 = a & ~(b ^ c))
+        lo = __builtin_amdgcn_bitop3_b32(lo, (u32)bal, mine, 0x90);
+        hi = __builtin_amdgcn_bitop3_b32(hi, (u32)(bal >> 32), mine, 0x90);
     }
     below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
     total = (u32)__popc(lo) + (u32)__popc(hi);
