@@ -235,7 +235,8 @@ __device__ __forceinline__ void rcx_bwt_pass(uint16_t* arr, uint16_t* cnt, u32* 
         u32 below_, total_;                                                                                            \
         rcx_bwt_match8(d_, below_, total_);                                                                            \
         const u32 old_ = mine[d_];                                                                                     \
-        if (below_ + 1 == total_) mine[d_] = (uint16_t)(old_ + total_); /* the highest of the peers */                 \
+        /* the highest of the peers writes -- or, where the match only runs on piled-up batches, all of them (the same) */ \
+        if (ATOMIC || below_ + 1 == total_) mine[d_] = (uint16_t)(old_ + total_);                                      \
         held[IT] |= (old_ + below_) << 16;                                                                             \
         if (ATOMIC) PILED = __builtin_amdgcn_ballot_w64(total_ > RCX_BWT_PILE) != 0;                                   \
     }
