@@ -158,7 +158,8 @@ def test_row_past_the_block_is_refused(ctx):
 def test_device_calls_any_alignment_and_capacity(ctx):
     from cpprcoder_amd import rcx
     o = oracle_lib.oracle()
-    data = workloads.by_name("canterbury", 5 * BLOCK + 100, 3)
+    # text, and blocks of long runs (which start from run keys: another path through the block in LDS), and a tail
+    data = np.concatenate([workloads.by_name("canterbury", 3 * BLOCK, 3), workloads.by_name("runs", 2 * BLOCK + 100, 4)])
     want = o.bwt_encode(data, threads=8)
     for off_in, off_out in ((0, 0), (1, 0), (0, 3), (7, 9), (15, 1)):
         src = torch.zeros(len(data) + 64, dtype=torch.uint8, device="cuda")
