@@ -453,11 +453,34 @@ __device__ __forceinline__ u32 rcx_bwt_place(uint16_t* sa, uint16_t* rk, const u
     for (u32 i = 0; i < L; ++i) in_list |= (q0 + i < count ? 1u : 0u) << i;
     // index + 1 of the last old / new start at or before each entry: inside the thread from the bits, before it a running maximum
     const u32 o_own = olds & own & in_list, n_own = news & own & in_list;
-    const u32 o_before = rcx_bwt_block_excl_max(o_own ? q0 + 32u - (u32)__clz(o_own) : 0u, misc);
-    const u32 n_before = rcx_bwt_block_excl_max(n_own ? q0 + 32u - (u32)__clz(n_own) : 0u, misc);
     const u32 alone = news & (news >> 1) & own & in_list;
-    const u32 sums = rcx_bwt_block_sum(((u32)__popc(n_own) - (u32)__popc(o_own)) | (((u32)__popc(in_list) - (u32)__popc(alone)) << 16), misc);
-    // (every RK has been read: the barriers above)
+    // two running maxima and two sums across the workgroup in one exchange (misc: 48 dwords, one pair of barriers)
+    u32 o_before, n_before, sums;
+    {
+        const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+        const u32 o_run = rcx_bwt_wave_incl_max(o_own ? q0 + 32u - (u32)__clz(o_own) : 0u);
+        const u32 n_run = rcx_bwt_wave_incl_max(n_own ? q0 + 32u - (u32)__clz(n_own) : 0u);
+        const u32 s_run = rcx_bwt_wave_incl_sum(((u32)__popc(n_own) - (u32)__popc(o_own)) | (((u32)__popc(in_list) - (u32)__popc(alone)) << 16));
+        o_before = rcx_bwt_wave_prev(o_run);
+        n_before = rcx_bwt_wave_prev(n_run);
+        if (lane == 63) {
+            misc[w] = o_run;
+            misc[16 + w] = n_run;
+            misc[32 + w] = s_run;
+        }
+        __syncthreads(); // (every RK has been read)
+        sums = 0;
+#pragma unroll
+        for (u32 i = 0; i < RCX_BWT_WAVES; ++i) {
+            const u32 o = misc[i], n = misc[16 + i];
+            if (i < w) {
+                o_before = o_before > o ? o_before : o;
+                n_before = n_before > n ? n_before : n;
+            }
+            sums += misc[32 + i];
+        }
+        // (misc is next written behind the barrier at the end of this function)
+    }
 #pragma unroll
     for (u32 i = 0; i < L; ++i) {
         if ((in_list >> i) & 1u) {
