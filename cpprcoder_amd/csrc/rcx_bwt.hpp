@@ -166,7 +166,8 @@ __device__ __forceinline__ u32 rcx_bwt_wave_incl_max(u32 v)
 // the value of the lane before (0 for lane 0): wave_shr:1
 __device__ __forceinline__ u32 rcx_bwt_wave_prev(u32 v) { return rcx_bwt_dpp0<0x138, 0xF, 0xF>(v); }
 
-// exclusive prefix sum over the workgroup (all 1024 threads call it); misc: 16 dwords
+// exclusive prefix sum over the workgroup (all 1024 threads call it); misc: 16 dwords, which the caller must not write
+// again before its next barrier (both callers have one right behind)
 __device__ __forceinline__ u32 rcx_bwt_block_excl(u32 v, u32* misc)
 {
     const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
@@ -179,7 +180,6 @@ __device__ __forceinline__ u32 rcx_bwt_block_excl(u32 v, u32* misc)
         const u32 t = misc[i];
         base += i < w ? t : 0u;
     }
-    __syncthreads();
     return base + incl - v;
 }
 
@@ -302,24 +302,6 @@ __device__ __forceinline__ void rcx_bwt_rows32(const uint16_t* sa, u32 k0, u32 (
         s[8 * q + 6] = v.w & 0xFFFFu;
         s[8 * q + 7] = v.w >> 16;
     }
-}
-
-// exclusive running maximum over the workgroup (values >= 0, "nothing yet" = 0); misc: 16 dwords
-__device__ __forceinline__ u32 rcx_bwt_block_excl_max(u32 v, u32* misc)
-{
-    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const u32 run = rcx_bwt_wave_incl_max(v);
-    const u32 before = rcx_bwt_wave_prev(run);
-    if (lane == 63) misc[w] = run;
-    __syncthreads();
-    u32 carry = before;
-#pragma unroll
-    for (u32 i = 0; i < RCX_BWT_WAVES; ++i) {
-        const u32 m = misc[i];
-        if (i < w) carry = carry > m ? carry : m;
-    }
-    __syncthreads();
-    return carry;
 }
 
 // sum over the workgroup; misc: 16 dwords
