@@ -304,7 +304,7 @@ __device__ __forceinline__ void rcx_bwt_rows32(const uint16_t* sa, u32 k0, u32 (
     }
 }
 
-// sum over the workgroup; misc: 16 dwords
+// sum over the workgroup; misc: 16 dwords (not to be written again before the caller's next barrier)
 __device__ __forceinline__ u32 rcx_bwt_block_sum(u32 v, u32* misc)
 {
     const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
@@ -314,7 +314,6 @@ __device__ __forceinline__ u32 rcx_bwt_block_sum(u32 v, u32* misc)
     u32 all = 0;
 #pragma unroll
     for (u32 i = 0; i < RCX_BWT_WAVES; ++i) all += misc[i];
-    __syncthreads();
     return all;
 }
 
