@@ -684,27 +684,32 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
                 if (now == groups) break; // nothing split: the block is periodic, `groups` is its period
                 groups = now;
             } else {
-                const bool big = open > 1024u * RCX_BWT_LIST_SMALL;
-                const u32 count = rcx_bwt_collect(sa, rk, lst, misc, h, 1024u * (big ? RCX_BWT_LIST_BIG : RCX_BWT_LIST_SMALL));
+                // (three lengths of list -- 11264, 3072, 1024 entries -- so that the last rounds, with a few hundred
+                // rotations open, pay for a few hundred)
+                const u32 iters = open > 1024u * RCX_BWT_LIST_SMALL ? RCX_BWT_LIST_BIG : open > 1024u ? RCX_BWT_LIST_SMALL : 1u;
+                const u32 count = rcx_bwt_collect(sa, rk, lst, misc, h, 1024u * iters);
                 RCX_BWT_PHASE(4) // collect
                 // by group: a padding entry (0xFFFF) sorts behind everything
                 const auto same = [](u32 x) { return x; };
+                const auto by_group = [&](u32 down) { return [&, down](u32 e) { return e == 0xFFFFu ? 0xFFu : (((u32)rk[e & RCX_BWT_MASK] & RCX_BWT_MASK) >> down) & 0xFFu; }; };
                 u32 splits;
-                if (big) {
+                if (iters == RCX_BWT_LIST_BIG) {
 #pragma nounroll
-                    for (u32 down = 0; down < 16; down += 8)
-                        rcx_bwt_pass<RCX_BWT_LIST_BIG, ATOMIC>(lst, cnt, misc, same, [&](u32 e) { return e == 0xFFFFu ? 0xFFu : (((u32)rk[e & RCX_BWT_MASK] & RCX_BWT_MASK) >> down) & 0xFFu; });
+                    for (u32 down = 0; down < 16; down += 8) rcx_bwt_pass<RCX_BWT_LIST_BIG, ATOMIC>(lst, cnt, misc, same, by_group(down));
                     RCX_BWT_PHASE(5) // list passes (long list)
                     open = rcx_bwt_place<RCX_BWT_LIST_BIG>(sa, rk, lst, misc, h, count, splits);
-                    RCX_BWT_PHASE(7) // place
-                } else {
+                } else if (iters == RCX_BWT_LIST_SMALL) {
 #pragma nounroll
-                    for (u32 down = 0; down < 16; down += 8)
-                        rcx_bwt_pass<RCX_BWT_LIST_SMALL, ATOMIC>(lst, cnt, misc, same, [&](u32 e) { return e == 0xFFFFu ? 0xFFu : (((u32)rk[e & RCX_BWT_MASK] & RCX_BWT_MASK) >> down) & 0xFFu; });
+                    for (u32 down = 0; down < 16; down += 8) rcx_bwt_pass<RCX_BWT_LIST_SMALL, ATOMIC>(lst, cnt, misc, same, by_group(down));
                     RCX_BWT_PHASE(6) // list passes (short list)
                     open = rcx_bwt_place<RCX_BWT_LIST_SMALL>(sa, rk, lst, misc, h, count, splits);
-                    RCX_BWT_PHASE(7)
+                } else {
+#pragma nounroll
+                    for (u32 down = 0; down < 16; down += 8) rcx_bwt_pass<1u, ATOMIC>(lst, cnt, misc, same, by_group(down));
+                    RCX_BWT_PHASE(6)
+                    open = rcx_bwt_place<1u>(sa, rk, lst, misc, h, count, splits);
                 }
+                RCX_BWT_PHASE(7) // place
                 if (splits == 0) break; // periodic (cannot happen with a list this short, but it is the same test)
                 groups += splits;
             }
