@@ -24,7 +24,7 @@
 // Rounds get cheaper: a rotation that is alone in its group has its final row (RK carries a flag for it), and once the
 // rotations that are not fit a list in LDS (11264 entries; text gets there after two or three rounds) a round only
 // touches those: the SA[k] - h that are still open are collected in row order, that list is sorted by group with the
-// same two counting passes -- a third or a tenth as long -- and lands in the open rows, which it fills exactly.
+// same two counting passes -- a third, a tenth or a thirtieth as long -- and lands in the open rows, which it fills exactly.
 //
 // A stable counting pass of 32768 keys by 1024 lanes: wave w owns keys [2048 w, 2048 w + 2048), 64 at a time in index
 // order; per wave and digit a running count in LDS gives every key its rank among the wave's earlier keys with the
