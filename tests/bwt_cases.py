@@ -55,6 +55,8 @@ def cases() -> dict[str, np.ndarray]:
     c["period 4096, ramp"] = _tile((np.arange(4096) // 16).astype(np.uint8))
     c["period 2048, sorted"] = _tile(np.sort(mix(2048, 6)))
     c["skewed bytes"] = np.minimum(mix(BLOCK, 101), 24).astype(np.uint8)   # not periodic, heapsort all the same
+    # long runs of one byte (1 .. 4096 long): on the GPU such blocks start from run keys, not from two bytes
+    c["long runs, two blocks"] = np.repeat(mix(64, 23), 1 + (mix(64, 24).astype(np.uint32) * 16 + mix(64, 25) % 16))[: 2 * BLOCK]
     c["three blocks: periodic, random, zeros"] = np.concatenate([periodic(8, 21), mix(BLOCK, 22), np.zeros(BLOCK + 77, np.uint8)])
     return c
 
