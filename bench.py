@@ -3,6 +3,9 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Both forms work for N > 1: typed plainly, this process starts the N ranks itself (one fresh process per GPU, RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous), never touches the GPU, relays rank 0's line and exits
+non-zero if any rank does.
 
 One "step" = one pass of the hot path over one batch of synthetic input that is already
 resident in HBM: encode 1 GiB (per GPU) of 64 KiB blocks into the compacted stream
@@ -106,6 +109,108 @@ def cpu_baseline(data: np.ndarray, block: int, coder: int = 0, blksort: bool = F
     }, sizes
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """`python bench.py --gpus N` typed plainly: start N fresh rank processes (this one has not touched the GPU and never
+    does), hand rank 0's stdout through, stderr of all ranks as it comes.  Returns the exit code: 0 only if every rank's is."""
+    import subprocess
+    import threading
+    port = _free_port()
+    procs, first_line = [], []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    reader = threading.Thread(target=lambda: first_line.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    code = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0 and code == 0:
+                code = rc if rc > 0 else 1
+                print(f"bench.py: rank {r} exited with {rc}; stopping the other ranks", file=sys.stderr)
+                for o in alive:
+                    procs[o].terminate()  # (the very processes started above, by handle)
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    out = (first_line[0] if first_line else b"").decode(errors="replace")
+    if code == 0:
+        sys.stdout.write(out if out.endswith("\n") or not out else out + "\n")
+        sys.stdout.flush()
+    return code
+
+
+def issue_ceiling(rec: dict, kernel: str, symbols_per_chain: int):
+    """SURVEY.md section 7, hard part 5: the ceiling that binds these kernels is instruction issue along a block's
+    serial chain, not HBM.  From the recorded SQ counters of the kernel (profiles/pmc_traffic.json, the same separate
+    rocprofv3 --pmc passes `traffic` comes from): vector instructions per symbol and wave, the wave's cycles per symbol
+    (SQ_WAVE_CYCLES counts in units of 4 cycles), and the fraction of those cycles in which a vector instruction of the
+    wave was issued (each takes its SIMD 4 cycles, so VALU instructions x 4 / cycles = SQ_INSTS_VALU / SQ_WAVE_CYCLES)."""
+    c = rec.get(kernel, {}).get("counters_per_launch", {})
+    need = ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_WAVE_CYCLES")
+    if not all(k in c and c[k] for k in need):
+        return None
+    waves, symbols = c["SQ_WAVES"], float(symbols_per_chain)
+    out = {
+        "vector_insts_per_symbol_wave": round(c["SQ_INSTS_VALU"] / waves / symbols, 2),
+        "cycles_per_symbol": round(4.0 * c["SQ_WAVE_CYCLES"] / waves / symbols, 1),
+        "frac_of_issue": round(c["SQ_INSTS_VALU"] / c["SQ_WAVE_CYCLES"], 4),
+        "waves": int(waves),
+    }
+    if c.get("SQ_ACTIVE_INST_ANY"):
+        out["frac_issuing_any_instruction"] = round(c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4)
+    if c.get("SQ_LDS_BANK_CONFLICT") and c.get("SQ_LDS_IDX_ACTIVE"):
+        out["lds_bank_conflict_frac"] = round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 4)
+    return out
+
+
+def end_to_end(ctx, host_src: np.ndarray, block: int, coder: int):
+    """the PCIe-inclusive rate, separately -- never `value`.  The host-buffer calls
+    (rcx_encode_blocks / rcx_decode_blocks, csrc/rcx_host.hpp) on pageable host memory that exists before the clock starts,
+    as the reference's harness holds its buffers (test/main.cpp:321-336): one pass with a destination whose pages have never
+    been touched, then the best of three with the same buffers."""
+    from cpprcoder_amd import rcx
+    n = len(host_src)
+    nblocks = rcx.block_count(n, block)
+    dst = np.empty(rcx.encode_bound(n, block, coder), dtype=np.uint8)
+    out = np.empty(n, dtype=np.uint8)
+    offsets = np.zeros(nblocks + 1, dtype=np.uint64)
+    rows = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        size = ctx.encode_blocks_into(host_src, block, dst, offsets, coder)
+        t1 = time.perf_counter()
+        got = ctx.decode_blocks_into(dst, size, offsets, block, out, coder)
+        t2 = time.perf_counter()
+        rows.append((t1 - t0, t2 - t1))
+    ok = got == n and bool(np.array_equal(out, host_src))
+    enc, dec = min(r[0] for r in rows[1:]), min(r[1] for r in rows[1:])
+    link_ms = n / 57e9 * 1e3
+    return {
+        "encode_MBps": round(n / 1e6 / enc, 1), "decode_MBps": round(n / 1e6 / dec, 1),
+        "encode_MBps_fresh_destination": round(n / 1e6 / rows[0][0], 1), "decode_MBps_fresh_destination": round(n / 1e6 / rows[0][1], 1),
+        "roundtrip_ok": ok, "bytes": n,
+        "what": "rcx_encode_blocks / rcx_decode_blocks: pageable host buffers in and out, chunks of whole blocks with copy in, "
+                "kernels and copy out overlapped (csrc/rcx_host.hpp); best of 3 with reused buffers, and the first pass whose "
+                "destination pages had never been touched",
+        "limit": f"the link: {n >> 20} MiB cross it each way at about 57 GB/s ({link_ms:.1f} ms, both directions at once), plus one "
+                 "chunk's kernels (a block's serial chain: 5.6 ms encode, 11.1 ms decode at 64 KiB blocks) and one chunk's copy back "
+                 "that nothing can overlap; a fresh destination adds its page faults (host side)",
+    }
+
+
 # The contract is ONE line on stdout.  RCCL prints a version banner to stdout when a communicator is created
 # (and other libraries may chat as well): everything written to file descriptor 1 during the run goes to stderr,
 # and the JSON line is written to the real stdout at the end.
@@ -120,7 +225,6 @@ def _stdout_to_stderr() -> None:
 
 
 def main() -> None:
-    _stdout_to_stderr()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -138,7 +242,24 @@ def main() -> None:
     ap.add_argument("--cpu-sample-mib", type=int, default=256)
     ap.add_argument("--exchange", action="store_true",
                     help="run the N>1 exchange step (allgatherv over RCCL) even with one rank: rehearses that code path on a 1-GPU box")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="rehearse the launcher without a GPU: every rank prints the environment it was started with and exits")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurement")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_launch):
+        # typed plainly: this process only starts the ranks (it has imported nothing that initialises HIP)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.dry_launch:
+        keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
+        mine = {k: os.environ.get(k) for k in keys}
+        print(json.dumps({"dry_launch": True, "gpus": args.gpus, "env": mine}), file=sys.stdout if mine["RANK"] == "0" else sys.stderr, flush=True)
+        if os.environ.get("RCX_BENCH_DRY_FAIL_RANK") == mine["RANK"]:  # (the launcher's test: a rank that fails)
+            raise SystemExit(3)
+        if os.environ.get("RCX_BENCH_DRY_FAIL_RANK"):
+            time.sleep(2.0)  # (the others are still at work when it does)
+        return
+    _stdout_to_stderr()
 
     import torch
     import torch.distributed as dist
@@ -147,9 +268,7 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus:  # (started by torch.distributed.run with another count: the environment is what counts)
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -286,7 +405,7 @@ def main() -> None:
         # HBM bytes per launch of the dominant kernel from the PMC passes (separate rocprofv3 --pmc runs cannot happen
         # inside this process): replayed from profiles/pmc_traffic.json, and only if that file was recorded on the
         # workload this run is on -- otherwise null.
-        traffic, traffic_source = None, None
+        traffic, traffic_source, ceiling = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
@@ -295,6 +414,9 @@ def main() -> None:
                 if (cfg.get("workload"), cfg.get("bytes"), cfg.get("block")) == (args.workload, n, block):
                     traffic = rec.get(dom, {}).get("hbm_bytes_per_launch")
                     traffic_source = f"profiles/pmc_traffic.json ({cfg.get('recorded', 'an earlier rocprofv3 --pmc run')} on this workload), not measured by this run"
+                    ceiling = issue_ceiling(rec, dom, block)
+                    if ceiling:
+                        ceiling["source"] = traffic_source
                 else:
                     traffic_source = "none: profiles/pmc_traffic.json was recorded on another workload"
             except Exception:
@@ -322,8 +444,10 @@ def main() -> None:
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": int(algo_bytes),
+                         "issue_ceiling": ceiling,
                          "note": "per-block coding is a serial chain per symbol; the ceiling that actually binds is "
-                                 "blocks_in_flight x clock / cycles_per_symbol (DESIGN.md), not HBM"},
+                                 "blocks_in_flight x clock / cycles_per_symbol (DESIGN.md), not HBM: issue_ceiling says how much of a "
+                                 "wave's time along that chain goes into issuing its vector instructions"},
             "workload_gen_s": round(gen_s, 2),
         }
         if exchange and gather_ms:
@@ -349,6 +473,11 @@ def main() -> None:
                 line["cpu_baseline"]["block_sizes_equal_gpu"] = bool(np.array_equal(gpu_sizes, cpu_sizes[:k].astype(np.int64)))
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        if world == 1 and not args.no_end_to_end and not args.blksort:
+            try:
+                line["end_to_end"] = end_to_end(ctx, host_src, block, coder)
+            except Exception as e:  # a report beside the number, never a reason to lose it
+                line["end_to_end"] = {"encode_MBps": None, "decode_MBps": None, "what": f"failed: {e}"}
         os.write(_REAL_STDOUT, (json.dumps(line) + "\n").encode())
 
     ctx.close()

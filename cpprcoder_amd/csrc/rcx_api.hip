@@ -29,6 +29,8 @@ struct EventPair {
     int what;
 };
 
+struct HostPipe; // rcx_host.hpp: streams, threads' staging and bookkeeping of the host-buffer entry points
+
 } // namespace
 
 struct rcx_ctx {
@@ -67,6 +69,7 @@ struct rcx_ctx {
     u64 h_out_bytes = 0;
     u64* h_off = nullptr;
     u64 h_off_count = 0;
+    HostPipe* pipe = nullptr;   // made by the first host-buffer call that is large enough to be cut into chunks
     // timing
     bool timing = false;
     std::vector<EventPair> pending;
@@ -191,6 +194,22 @@ int ensure_redo(rcx_ctx* c, u64 nblocks)
     return r;
 }
 
+// Which part of the context's per-block scratch a set of launches uses, and in which launch shape.
+struct ScratchRange {
+    u64 first = 0;       // blocks into slots / sizes / starts / models / redo
+    bool packed = false; // full workgroups and waves whatever the block count (chunks that share the machine)
+};
+struct ScratchView {
+    u8* slots;
+    u32* sizes;
+    u32* starts;
+    u32* models;
+    u32* redo;
+};
+int encode_range(rcx_ctx* c, int coder, const void* d_src, u64 n, u32 block, void* d_dst, u64 dst_cap, u64* d_offsets, hipStream_t s, ScratchRange rg);
+int decode_range(rcx_ctx* c, int coder, const void* d_comp, u64 comp_size, const u64* d_offsets, u64 nblocks, u32 block, u64 n, void* d_dst,
+                 hipStream_t s, ScratchRange rg);
+
 bool is_rans(int coder) { return coder == RCX_CODER_RANS || coder == RCX_CODER_RANS8; }
 bool coder_ok(int coder) { return coder == RCX_CODER_ADAPTIVE || coder == RCX_CODER_STATIC || is_rans(coder); }
 
@@ -220,6 +239,8 @@ int reserve(rcx_ctx* c, u64 n, u32 block, int coder = RCX_CODER_ADAPTIVE)
 }
 
 } // namespace
+
+#include "rcx_host.hpp"
 
 extern "C" {
 
@@ -320,6 +341,7 @@ void rcx_ctx_destroy(rcx_ctx* c)
     if (c->h_in) (void)hipFree(c->h_in);
     if (c->h_out) (void)hipFree(c->h_out);
     if (c->h_off) (void)hipFree(c->h_off);
+    host_pipe_destroy(c->pipe);
     delete c;
 }
 
@@ -368,7 +390,25 @@ int rcx_encode_blocks_device(rcx_ctx* c, int coder, const void* d_src, uint64_t 
     if (nblocks > 0x7FFFFFFFull) return RCX_E_ARG; // grid.x limit with 8 blocks per workgroup to spare
     int r = reserve(c, n, block, coder);
     if (r != RCX_OK) return r;
+    return encode_range(c, coder, d_src, n, block, d_dst, dst_cap, d_offsets, s, ScratchRange{});
+}
+
+} // extern "C"
+
+namespace
+{
+
+// The encode launches for blocks whose scratch (slots, sizes, starts, models, redo) begins `rg.first` blocks into the
+// context's arrays, which the caller has reserved.  The many-block call above is the whole range; the host-buffer
+// pipeline (rcx_host.hpp) runs several chunks of one buffer at once, each on its own stream and its own part of the
+// scratch, `packed` = every workgroup / wave carries its full load of blocks, so that chunks share the machine.
+int encode_range(rcx_ctx* c, int coder, const void* d_src, u64 n, u32 block, void* d_dst, u64 dst_cap, u64* d_offsets, hipStream_t s,
+                 ScratchRange rg)
+{
+    const u64 nblocks = rcx_block_count(n, block);
     const u64 slot = rcx_block_bound_for(coder, block);
+    ScratchView v{c->slots + rg.first * slot, c->sizes + rg.first, c->starts ? c->starts + rg.first : nullptr,
+                  c->models ? c->models + rg.first * RCX_RANS_MODEL_DW : nullptr, c->redo + rg.first};
     // Static coder: with fewer than 32768 blocks (two one-wave workgroups per CU) the three-wave kernel, which
     // spreads 64 blocks over three SIMDs, is faster (157 vs 112 GB/s at 16384 blocks); with more, the one-wave
     // kernel fills the machine by itself (202 vs 157 GB/s at 32768 blocks).
@@ -379,12 +419,12 @@ int rcx_encode_blocks_device(rcx_ctx* c, int coder, const void* d_src, uint64_t 
             const u64 per_wg = 4 * RCX_RANS_BLOCKS;
             const u32 grid = (u32)((nblocks + per_wg - 1) / per_wg);
             if (coder == RCX_CODER_RANS8)
-                hipLaunchKernelGGL(rcx_enc_rans_k<true>, dim3(grid), dim3(256), 0, s, static_cast<const u8*>(d_src), n, block, nblocks, c->slots,
-                                   slot, c->sizes, c->starts, c->status);
+                hipLaunchKernelGGL(rcx_enc_rans_k<true>, dim3(grid), dim3(256), 0, s, static_cast<const u8*>(d_src), n, block, nblocks, v.slots,
+                                   slot, v.sizes, v.starts, c->status);
             else {
                 // one state per block = one chain per block: the model by octets, then the coding loop one lane per
                 // block, `lanes` blocks per wave so that every SIMD has a wave before any wave carries 64
-                hipLaunchKernelGGL(rcx_rans_model_k<14>, dim3(grid), dim3(256), 0, s, static_cast<const u8*>(d_src), n, block, nblocks, c->models);
+                hipLaunchKernelGGL(rcx_rans_model_k<14>, dim3(grid), dim3(256), 0, s, static_cast<const u8*>(d_src), n, block, nblocks, v.models);
                 // 16 blocks per wave, four waves per workgroup, 2 KiB of LDS per block: 128 KiB = one workgroup per CU.
                 // Measured (profiles/r02_sweep_rans.jsonl, RCX_RANS1_LANES): thinner waves on more CUs are SLOWER here
                 // (4096 blocks of 256 KiB: 34 ms with 16 lanes on 64 CUs, 99 ms with 4 lanes on 256 CUs).
@@ -399,41 +439,41 @@ int rcx_encode_blocks_device(rcx_ctx* c, int coder, const void* d_src, uint64_t 
                     c->rans1_lds_set = true;
                 }
                 hipLaunchKernelGGL(rcx_enc_rans1_k, dim3(grid1), dim3(64 * RCX_RANS1_ENC_WAVES), lds_bytes, s, static_cast<const u8*>(d_src), n, block,
-                                   nblocks, static_cast<const u32*>(c->models), c->slots, slot, c->sizes, c->starts, c->status, lanes);
+                                   nblocks, static_cast<const u32*>(v.models), v.slots, slot, v.sizes, v.starts, c->status, lanes);
             }
         } else if (static3) {
-            const u32 lanes = encode_lanes(c, nblocks);
+            const u32 lanes = rg.packed ? RCX_LANES : encode_lanes(c, nblocks);
             const u32 grid = (u32)((nblocks + lanes - 1) / lanes);
             hipLaunchKernelGGL(rcx_enc_static3_k, dim3(grid), dim3(RCX_ST3_THREADS), 0, s, static_cast<const u8*>(d_src), n, block,
-                               nblocks, c->slots, slot, c->sizes, c->status, c->redo, lanes);
+                               nblocks, v.slots, slot, v.sizes, c->status, v.redo, lanes);
         } else if (coder == RCX_CODER_STATIC) {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_enc_static_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block, nblocks,
-                               c->slots, slot, c->sizes, c->status, static_cast<const u32*>(nullptr));
+                               v.slots, slot, v.sizes, c->status, static_cast<const u32*>(nullptr));
         } else if (c->enc_variant == 3) {
-            const u32 lanes = encode_lanes(c, nblocks);
+            const u32 lanes = rg.packed ? RCX_LANES : encode_lanes(c, nblocks);
             const u32 grid = (u32)((nblocks + lanes - 1) / lanes);
             hipLaunchKernelGGL(rcx_enc_mc5_k, dim3(grid), dim3(RCX_MC5_THREADS), 0, s, static_cast<const u8*>(d_src), n, block,
-                               nblocks, c->slots, slot, c->sizes, c->divtab, c->status, c->redo, lanes);
+                               nblocks, v.slots, slot, v.sizes, c->divtab, c->status, v.redo, lanes);
         } else if (c->enc_variant == 2) {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_enc_mc_k, dim3(grid), dim3(RCX_MC_THREADS), 0, s, static_cast<const u8*>(d_src), n, block, nblocks,
-                               c->slots, slot, c->sizes, c->divtab, c->status);
+                               v.slots, slot, v.sizes, c->divtab, c->status);
         } else if (c->enc_variant == 1) {
             const u32 grid = (u32)((nblocks + RCX_OCT_BLOCKS - 1) / RCX_OCT_BLOCKS);
             hipLaunchKernelGGL(rcx_enc_oct_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block, nblocks,
-                               c->slots, slot, c->sizes, c->divtab, c->status);
+                               v.slots, slot, v.sizes, c->divtab, c->status);
         } else {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_enc_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block,
-                               nblocks, c->slots, slot, c->sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr),
+                               nblocks, v.slots, slot, v.sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr),
                                static_cast<const u32*>(nullptr));
         }
         // (the second passes are part of the encode time: on adversarial data they are not free)
         if (static3) { // the same for the static coder
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_enc_static_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block, nblocks,
-                               c->slots, slot, c->sizes, c->status, static_cast<const u32*>(c->redo));
+                               v.slots, slot, v.sizes, c->status, static_cast<const u32*>(v.redo));
         }
         if (coder == RCX_CODER_ADAPTIVE && c->enc_variant == 3) {
             // Blocks in which a carry ran through more output bytes than the five-wave kernel keeps in LDS were
@@ -441,21 +481,25 @@ int rcx_encode_blocks_device(rcx_ctx* c, int coder, const void* d_src, uint64_t 
             // and every wave of this launch returns at once.
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_enc_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block,
-                               nblocks, c->slots, slot, c->sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr),
-                               static_cast<const u32*>(c->redo));
+                               nblocks, v.slots, slot, v.sizes, c->divtab, c->status, 0u, static_cast<u32*>(nullptr),
+                               static_cast<const u32*>(v.redo));
         }
     }
     {
         Timed t(c, s, RCX_T_SCAN);
-        hipLaunchKernelGGL(rcx_scan_sizes_k, dim3(1), dim3(1024), 0, s, c->sizes, nblocks, d_offsets, dst_cap, c->status);
+        hipLaunchKernelGGL(rcx_scan_sizes_k, dim3(1), dim3(1024), 0, s, v.sizes, nblocks, d_offsets, dst_cap, c->status);
     }
     {
         Timed t(c, s, RCX_T_SCATTER);
-        hipLaunchKernelGGL(rcx_scatter_k, dim3((u32)nblocks), dim3(256), 0, s, c->slots, slot, c->sizes, d_offsets,
-                           static_cast<u8*>(d_dst), dst_cap, is_rans(coder) ? static_cast<const u32*>(c->starts) : static_cast<const u32*>(nullptr));
+        hipLaunchKernelGGL(rcx_scatter_k, dim3((u32)nblocks), dim3(256), 0, s, v.slots, slot, v.sizes, d_offsets,
+                           static_cast<u8*>(d_dst), dst_cap, is_rans(coder) ? static_cast<const u32*>(v.starts) : static_cast<const u32*>(nullptr));
     }
     return hipGetLastError() == hipSuccess ? RCX_OK : RCX_E_HIP;
 }
+
+} // namespace
+
+extern "C" {
 
 int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t comp_size,
                              const uint64_t* d_offsets, uint64_t nblocks, uint32_t block,
@@ -468,6 +512,25 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
     if (nblocks > 0x7FFFFFFFull) return RCX_E_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(c->device));
+    if (!is_rans(coder)) {
+        int r = ensure_divtab(c, block);
+        if (r != RCX_OK) return r;
+        if ((r = ensure_redo(c, nblocks)) != RCX_OK) return r; // no-op after rcx_ctx_reserve
+    }
+    return decode_range(c, coder, d_comp, comp_size, d_offsets, nblocks, block, n, d_dst, s, ScratchRange{});
+}
+
+} // extern "C"
+
+namespace
+{
+
+// The decode launches for `nblocks` blocks whose redo marks begin `rg.first` entries into the context's array (see
+// encode_range); the divisor table and the redo array are in place.
+int decode_range(rcx_ctx* c, int coder, const void* d_comp, u64 comp_size, const u64* d_offsets, u64 nblocks, u32 block, u64 n, void* d_dst,
+                 hipStream_t s, ScratchRange rg)
+{
+    u32* const redo = c->redo ? c->redo + rg.first : nullptr;
     if (is_rans(coder)) {
         Timed t(c, s, RCX_T_DECODE);
         const u64 per_wg = 4 * RCX_RANS_BLOCKS;
@@ -476,7 +539,7 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
             hipLaunchKernelGGL(rcx_dec_rans8_k<4>, dim3(grid), dim3(256), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks,
                                block, n, static_cast<u8*>(d_dst), c->status);
         else {
-            const u32 quads = decode_quads(c, nblocks);
+            const u32 quads = rg.packed ? RCX_QUAD_BLOCKS : decode_quads(c, nblocks);
             const u64 per_wg1 = (u64)quads * RCX_QUAD_DEC_WAVES;
             const u32 grid1 = (u32)((nblocks + per_wg1 - 1) / per_wg1);
             hipLaunchKernelGGL(rcx_dec_rans1_quad_k<RCX_QUAD_DEC_WAVES>, dim3(grid1), dim3(64 * RCX_QUAD_DEC_WAVES), 0, s,
@@ -485,37 +548,34 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
         }
         return hipGetLastError() == hipSuccess ? RCX_OK : RCX_E_HIP;
     }
-    int r = ensure_divtab(c, block);
-    if (r != RCX_OK) return r;
     const bool quad = coder == RCX_CODER_ADAPTIVE && decode_lanes(c, nblocks) == 4;
     const bool squad = coder == RCX_CODER_STATIC && decode_lanes(c, nblocks) != 1;
-    if ((quad || squad) && (r = ensure_redo(c, nblocks)) != RCX_OK) return r; // no-op after rcx_ctx_reserve
     {
         Timed t(c, s, RCX_T_DECODE);
         if (coder == RCX_CODER_STATIC && decode_lanes(c, nblocks) != 1) {
-            const u32 quads = decode_quads(c, nblocks);
+            const u32 quads = rg.packed ? RCX_QUAD_BLOCKS : decode_quads(c, nblocks);
             const u64 per_wg = (u64)quads * RCX_QUAD_DEC_WAVES;
             const u32 grid = (u32)((nblocks + per_wg - 1) / per_wg);
             hipLaunchKernelGGL(rcx_dec_static_quad_k<RCX_QUAD_DEC_WAVES>, dim3(grid), dim3(64 * RCX_QUAD_DEC_WAVES), 0, s,
                                static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks, block, n, static_cast<u8*>(d_dst), c->status,
-                               c->redo, quads);
+                               redo, quads);
         } else if (coder == RCX_CODER_STATIC) {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_dec_static_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks,
                                block, n, static_cast<u8*>(d_dst), c->status, static_cast<u32*>(nullptr),
                                static_cast<const u32*>(nullptr));
         } else if (decode_lanes(c, nblocks) == 4) {
-            const u32 quads = decode_quads(c, nblocks);
+            const u32 quads = rg.packed ? RCX_QUAD_BLOCKS : decode_quads(c, nblocks);
             if (wide_workgroups(c, nblocks)) {
                 const u64 per_wg = (u64)quads * RCX_QUAD_DEC_WAVES;
                 const u32 grid = (u32)((nblocks + per_wg - 1) / per_wg);
                 hipLaunchKernelGGL(rcx_dec_quad_k<RCX_QUAD_DEC_WAVES>, dim3(grid), dim3(64 * RCX_QUAD_DEC_WAVES), 0, s,
                                    static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks, block, n, static_cast<u8*>(d_dst), c->divtab,
-                                   c->status, c->redo, quads);
+                                   c->status, redo, quads);
             } else {
                 const u32 grid = (u32)((nblocks + quads - 1) / quads);
                 hipLaunchKernelGGL(rcx_dec_quad_k<1>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks,
-                                   block, n, static_cast<u8*>(d_dst), c->divtab, c->status, c->redo, quads);
+                                   block, n, static_cast<u8*>(d_dst), c->divtab, c->status, redo, quads);
             }
         } else if (decode_lanes(c, nblocks) == 8) {
             if (wide_workgroups(c, nblocks)) {
@@ -542,16 +602,20 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_dec_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets,
                                nblocks, block, n, static_cast<u8*>(d_dst), c->divtab, c->status, static_cast<u32*>(nullptr),
-                               static_cast<const u32*>(c->redo));
+                               static_cast<const u32*>(redo));
         }
         if (squad) { // the same for the static coder: a target past the table or a symbol of count 0
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_dec_static_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks,
-                               block, n, static_cast<u8*>(d_dst), c->status, static_cast<u32*>(nullptr), static_cast<const u32*>(c->redo));
+                               block, n, static_cast<u8*>(d_dst), c->status, static_cast<u32*>(nullptr), static_cast<const u32*>(redo));
         }
     }
     return hipGetLastError() == hipSuccess ? RCX_OK : RCX_E_HIP;
 }
+
+} // namespace
+
+extern "C" {
 
 int rcx_encode_blocks(rcx_ctx* c, int coder, const uint8_t* src, uint64_t n, uint32_t block,
                       uint8_t* dst, uint64_t dst_cap, uint64_t* dst_size, uint64_t* offsets)
@@ -561,27 +625,74 @@ int rcx_encode_blocks(rcx_ctx* c, int coder, const uint8_t* src, uint64_t n, uin
     *dst_size = 0;
     if (!coder_ok(coder)) return RCX_E_ARG;
     const u64 nblocks = rcx_block_count(n, block);
+    if (nblocks > 0x7FFFFFFFull) return RCX_E_ARG;
     const u64 bound = rcx_encode_bound_for(coder, n, block);
+    const u64 cb = host_chunk_blocks(block, false, nblocks);
+    const u64 chunks = (nblocks + cb - 1) / cb;
     int r = grow(reinterpret_cast<void**>(&c->h_in), &c->h_in_bytes, n + 64);
     if (r != RCX_OK) return r;
     r = grow(reinterpret_cast<void**>(&c->h_out), &c->h_out_bytes, bound + 64);
     if (r != RCX_OK) return r;
     u64 off_bytes = c->h_off_count * sizeof(u64);
-    r = grow(reinterpret_cast<void**>(&c->h_off), &off_bytes, (nblocks + 1) * sizeof(u64));
+    r = grow(reinterpret_cast<void**>(&c->h_off), &off_bytes, (nblocks + chunks + 1) * sizeof(u64));
     if (r != RCX_OK) return r;
     c->h_off_count = off_bytes / sizeof(u64);
-    if (n) HIP_TRY(hipMemcpy(c->h_in, src, n, hipMemcpyHostToDevice));
-    r = rcx_encode_blocks_device(c, coder, c->h_in, n, block, c->h_out, bound, c->h_off, nullptr);
+    if (chunks < 2 || getenv("RCX_HOST_SERIAL")) { // one chunk: nothing to overlap
+        if (n) HIP_TRY(hipMemcpy(c->h_in, src, n, hipMemcpyHostToDevice));
+        r = rcx_encode_blocks_device(c, coder, c->h_in, n, block, c->h_out, bound, c->h_off, nullptr);
+        if (r != RCX_OK) return r;
+        r = rcx_ctx_sync_status(c, nullptr, nullptr);
+        if (r != RCX_OK) return r;
+        u64 total = 0;
+        HIP_TRY(hipMemcpy(&total, c->h_off + nblocks, sizeof(u64), hipMemcpyDeviceToHost));
+        *dst_size = total;
+        if (offsets) HIP_TRY(hipMemcpy(offsets, c->h_off, (nblocks + 1) * sizeof(u64), hipMemcpyDeviceToHost));
+        if (total > dst_cap) return RCX_E_CAPACITY;
+        if (total) HIP_TRY(hipMemcpy(dst, c->h_out, total, hipMemcpyDeviceToHost));
+        return RCX_OK;
+    }
+    // Chunks of `cb` blocks.  Chunk k is encoded into its own part of the device buffer (at its first block's slot
+    // offset) with its own table, which comes back with it; where it goes in `dst` is known once the chunks before it
+    // are: the drainers add the sizes up as the chunks finish.
+    HostPipe* p = nullptr;
+    if ((r = host_pipe_get(c, &p)) != RCX_OK) return r;
+    if ((r = host_pipe_words(p, nblocks + chunks + 1)) != RCX_OK) return r;
+    if ((r = reserve(c, n, block, coder)) != RCX_OK) return r;
+    const u64 slot = rcx_block_bound_for(coder, block);
+    u64 running = 0;
+    bool fits = true;
+    HostJob job;
+    job.chunks = chunks;
+    job.in = [&](u64 k) -> HostSpan {
+        const u64 at = k * cb * block;
+        return HostSpan{src + at, c->h_in + at, (n - at < cb * block) ? n - at : cb * block};
+    };
+    job.launch = [&](u64 k, hipStream_t s) -> int {
+        const u64 b0 = k * cb, nb = (nblocks - b0 < cb) ? nblocks - b0 : cb;
+        const u64 at = b0 * block, len = (n - at < cb * block) ? n - at : cb * block;
+        const int e = encode_range(c, coder, c->h_in + at, len, block, c->h_out + b0 * slot, nb * slot, c->h_off + b0 + k, s, ScratchRange{b0, true});
+        if (e != RCX_OK) return e;
+        return hipMemcpyAsync(p->words + b0 + k, c->h_off + b0 + k, (nb + 1) * sizeof(u64), hipMemcpyDeviceToHost, s) == hipSuccess ? RCX_OK : RCX_E_HIP;
+    };
+    job.out = [&](u64 k, HostSpan* span) -> int {
+        const u64 b0 = k * cb, nb = (nblocks - b0 < cb) ? nblocks - b0 : cb;
+        const u64* rel = p->words + b0 + k;
+        if (offsets)
+            for (u64 i = 0; i < nb; ++i) offsets[b0 + i] = running + rel[i];
+        const u64 bytes = rel[nb];
+        if (bytes > nb * slot || running + bytes > dst_cap) fits = false; // (a slot overflow is latched on the device as well)
+        *span = fits ? HostSpan{c->h_out + b0 * slot, dst + running, bytes} : HostSpan{};
+        running += bytes;
+        return RCX_OK;
+    };
+    job.work_streams = 2; // (measured: a third encode chunk in flight gains nothing and delays the copies back)
+    r = host_run(c, p, job);
+    const int latched = rcx_ctx_sync_status(c, nullptr, nullptr);
     if (r != RCX_OK) return r;
-    r = rcx_ctx_sync_status(c, nullptr, nullptr);
-    if (r != RCX_OK) return r;
-    u64 total = 0;
-    HIP_TRY(hipMemcpy(&total, c->h_off + nblocks, sizeof(u64), hipMemcpyDeviceToHost));
-    *dst_size = total;
-    if (offsets) HIP_TRY(hipMemcpy(offsets, c->h_off, (nblocks + 1) * sizeof(u64), hipMemcpyDeviceToHost));
-    if (total > dst_cap) return RCX_E_CAPACITY;
-    if (total) HIP_TRY(hipMemcpy(dst, c->h_out, total, hipMemcpyDeviceToHost));
-    return RCX_OK;
+    if (latched != RCX_OK) return latched;
+    *dst_size = running;
+    if (offsets) offsets[nblocks] = running;
+    return fits ? RCX_OK : RCX_E_CAPACITY;
 }
 
 int rcx_decode_blocks(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_size,
@@ -589,6 +700,7 @@ int rcx_decode_blocks(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
                       uint8_t* dst, uint64_t dst_cap, uint64_t* dst_size)
 {
     if (!c || !block_ok(block) || !dst_size || (nblocks && (!comp || !offsets || !dst))) return RCX_E_ARG;
+    if (!coder_ok(coder) || nblocks > 0x7FFFFFFFull) return RCX_E_ARG;
     HIP_TRY(hipSetDevice(c->device));
     *dst_size = 0;
     if (nblocks == 0) return RCX_OK;
@@ -608,13 +720,50 @@ int rcx_decode_blocks(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
     r = grow(reinterpret_cast<void**>(&c->h_off), &off_bytes, (nblocks + 1) * sizeof(u64));
     if (r != RCX_OK) return r;
     c->h_off_count = off_bytes / sizeof(u64);
-    HIP_TRY(hipMemcpy(c->h_in, comp, comp_size, hipMemcpyHostToDevice));
+    const u64 cb = host_chunk_blocks(block, true, nblocks);
+    const u64 chunks = (nblocks + cb - 1) / cb;
+    if (chunks < 2 || getenv("RCX_HOST_SERIAL")) {
+        HIP_TRY(hipMemcpy(c->h_in, comp, comp_size, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->h_off, offsets, (nblocks + 1) * sizeof(u64), hipMemcpyHostToDevice));
+        r = rcx_decode_blocks_device(c, coder, c->h_in, comp_size, c->h_off, nblocks, block, n, c->h_out, nullptr);
+        if (r != RCX_OK) return r;
+        r = rcx_ctx_sync_status(c, nullptr, nullptr);
+        if (r != RCX_OK) return r;
+        HIP_TRY(hipMemcpy(dst, c->h_out, n, hipMemcpyDeviceToHost));
+        *dst_size = n;
+        return RCX_OK;
+    }
+    // Chunks of `cb` blocks: a chunk's streams are one stretch of `comp` (the table says which), and they keep their
+    // place in the device copy, so the table goes over once and as it is.
+    for (u64 b = 0; b < nblocks; ++b)
+        if (offsets[b] > offsets[b + 1]) return RCX_E_CORRUPT; // (the host has the table: a chunk is offsets[b0] .. offsets[b1] of `comp`)
+    HostPipe* p = nullptr;
+    if ((r = host_pipe_get(c, &p)) != RCX_OK) return r;
+    if (!is_rans(coder)) {
+        if ((r = ensure_divtab(c, block)) != RCX_OK) return r;
+        if ((r = ensure_redo(c, nblocks)) != RCX_OK) return r;
+    }
     HIP_TRY(hipMemcpy(c->h_off, offsets, (nblocks + 1) * sizeof(u64), hipMemcpyHostToDevice));
-    r = rcx_decode_blocks_device(c, coder, c->h_in, comp_size, c->h_off, nblocks, block, n, c->h_out, nullptr);
+    HostJob job;
+    job.chunks = chunks;
+    job.in = [&](u64 k) -> HostSpan {
+        const u64 b0 = k * cb, b1 = (b0 + cb < nblocks) ? b0 + cb : nblocks;
+        return HostSpan{comp + offsets[b0], c->h_in + offsets[b0], offsets[b1] - offsets[b0]};
+    };
+    job.launch = [&](u64 k, hipStream_t s) -> int {
+        const u64 b0 = k * cb, nb = (nblocks - b0 < cb) ? nblocks - b0 : cb;
+        const u64 at = b0 * block, len = (n - at < cb * block) ? n - at : cb * block;
+        return decode_range(c, coder, c->h_in, comp_size, c->h_off + b0, nb, block, len, c->h_out + at, s, ScratchRange{b0, true});
+    };
+    job.out = [&](u64 k, HostSpan* span) -> int {
+        const u64 at = k * cb * block;
+        *span = HostSpan{c->h_out + at, dst + at, (n - at < cb * block) ? n - at : cb * block};
+        return RCX_OK;
+    };
+    r = host_run(c, p, job);
+    const int latched = rcx_ctx_sync_status(c, nullptr, nullptr);
     if (r != RCX_OK) return r;
-    r = rcx_ctx_sync_status(c, nullptr, nullptr);
-    if (r != RCX_OK) return r;
-    HIP_TRY(hipMemcpy(dst, c->h_out, n, hipMemcpyDeviceToHost));
+    if (latched != RCX_OK) return latched;
     *dst_size = n;
     return RCX_OK;
 }
@@ -1115,6 +1264,7 @@ int rcx_bwt_encode_device(rcx_ctx* c, const void* d_src, uint64_t n, void* d_dst
     const u8* src = static_cast<const u8*>(d_src);
     u8* dst = static_cast<u8*>(d_dst);
     if (blocks >> 32) return RCX_E_ARG; // (the block counters are 32 bits: 128 TiB)
+    if (c->pipe) c->pipe->bwt_ties_valid = false;
     HIP_TRY(hipMemsetAsync(c->ties, 0, 2 * sizeof(u32), s)); // the tie count and the forward kernel's block counter
     if (blocks) {
         Timed t(c, s, RCX_T_BWT_FORWARD);
@@ -1168,12 +1318,54 @@ int bwt_host(rcx_ctx* c, bool forward, const uint8_t* src, uint64_t n, uint8_t* 
     if (r != RCX_OK) return r;
     r = grow(reinterpret_cast<void**>(&c->h_out), &c->h_out_bytes, out + 64);
     if (r != RCX_OK) return r;
-    HIP_TRY(hipMemcpy(c->h_in, src, n, hipMemcpyHostToDevice));
-    r = forward ? rcx_bwt_encode_device(c, c->h_in, n, c->h_out, out, nullptr) : rcx_bwt_decode_device(c, c->h_in, n, c->h_out, out, nullptr);
+    // Chunks of 1024 whole blocks (32 MiB); what is left over after the last whole block travels with the last chunk.
+    // These kernels take blocks off a counter with one workgroup per CU, so a chunk's kernels take the chunk's share of
+    // the time and follow each other on ONE stream (they also share the context's list of periodic blocks).
+    const u64 unit_in = forward ? RCX_BWT_BLOCK : RCX_BWT_ENCODED, unit_out = forward ? RCX_BWT_ENCODED : RCX_BWT_BLOCK;
+    const u64 blocks = n / unit_in, cb = 1024;
+    const u64 chunks = (blocks + cb - 1) / cb;
+    if (c->pipe) c->pipe->bwt_ties_valid = false;
+    if (chunks < 2 || getenv("RCX_HOST_SERIAL")) {
+        HIP_TRY(hipMemcpy(c->h_in, src, n, hipMemcpyHostToDevice));
+        r = forward ? rcx_bwt_encode_device(c, c->h_in, n, c->h_out, out, nullptr) : rcx_bwt_decode_device(c, c->h_in, n, c->h_out, out, nullptr);
+        if (r != RCX_OK) return r;
+        r = rcx_ctx_sync_status(c, nullptr, nullptr);
+        if (r != RCX_OK) return r;
+        HIP_TRY(hipMemcpy(dst, c->h_out, out, hipMemcpyDeviceToHost));
+        return RCX_OK;
+    }
+    HostPipe* p = nullptr;
+    if ((r = host_pipe_get(c, &p)) != RCX_OK) return r;
+    if ((r = host_pipe_words(p, chunks + 1)) != RCX_OK) return r;
+    if ((r = rcx_bwt_reserve(c, forward ? n : 0)) != RCX_OK) return r;
+    auto in_bytes = [&](u64 k) { return k + 1 < chunks ? cb * unit_in : n - k * cb * unit_in; };
+    auto out_bytes = [&](u64 k) { return k + 1 < chunks ? cb * unit_out : out - k * cb * unit_out; };
+    HostJob job;
+    job.chunks = chunks;
+    job.work_streams = 1;
+    job.in = [&](u64 k) -> HostSpan { return HostSpan{src + k * cb * unit_in, c->h_in + k * cb * unit_in, in_bytes(k)}; };
+    job.launch = [&](u64 k, hipStream_t s) -> int {
+        const u8* from = c->h_in + k * cb * unit_in;
+        u8* to = c->h_out + k * cb * unit_out;
+        const int e = forward ? rcx_bwt_encode_device(c, from, in_bytes(k), to, out_bytes(k), s) : rcx_bwt_decode_device(c, from, in_bytes(k), to, out_bytes(k), s);
+        if (e != RCX_OK || !forward) return e;
+        // how many of the chunk's blocks were periodic (rcx_bwt_last_ties adds the chunks up)
+        p->words[k] = 0;
+        return hipMemcpyAsync(p->words + k, c->ties, sizeof(u32), hipMemcpyDeviceToHost, s) == hipSuccess ? RCX_OK : RCX_E_HIP;
+    };
+    job.out = [&](u64 k, HostSpan* span) -> int {
+        *span = HostSpan{c->h_out + k * cb * unit_out, dst + k * cb * unit_out, out_bytes(k)};
+        return RCX_OK;
+    };
+    r = host_run(c, p, job);
+    const int latched = rcx_ctx_sync_status(c, nullptr, nullptr);
     if (r != RCX_OK) return r;
-    r = rcx_ctx_sync_status(c, nullptr, nullptr);
-    if (r != RCX_OK) return r;
-    HIP_TRY(hipMemcpy(dst, c->h_out, out, hipMemcpyDeviceToHost));
+    if (latched != RCX_OK) return latched;
+    if (forward) {
+        p->bwt_ties = 0;
+        for (u64 k = 0; k < chunks; ++k) p->bwt_ties += p->words[k];
+        p->bwt_ties_valid = true;
+    }
     return RCX_OK;
 }
 } // namespace
@@ -1193,6 +1385,10 @@ int rcx_bwt_last_ties(rcx_ctx* c, uint64_t* count)
     if (!c || !count) return RCX_E_ARG;
     *count = 0;
     if (!c->ties) return RCX_OK;
+    if (c->pipe && c->pipe->bwt_ties_valid) { // the last forward call was a host-buffer call made in chunks
+        *count = c->pipe->bwt_ties;
+        return RCX_OK;
+    }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
     u32 v = 0;

@@ -215,6 +215,29 @@ class Context:
         _check(st, "rcx_encode_blocks")
         return dst[: size.value], offsets
 
+    def encode_blocks_into(self, src: np.ndarray, block: int, dst: np.ndarray, offsets: np.ndarray, coder: int = CODER_ADAPTIVE) -> int:
+        """rcx_encode_blocks with the caller's buffers, as a C++ caller holds them (test/main.cpp:321-336 makes its
+        streams before the clock starts): src uint8[n], dst uint8[>= encode_bound], offsets uint64[nblocks+1] -> size."""
+        assert src.dtype == np.uint8 and dst.dtype == np.uint8 and offsets.dtype == np.uint64
+        assert src.flags.c_contiguous and dst.flags.c_contiguous and offsets.flags.c_contiguous
+        assert len(offsets) >= block_count(len(src), block) + 1
+        size = C.c_uint64()
+        st = lib().rcx_encode_blocks(self._h, coder, src.ctypes.data, len(src), block, dst.ctypes.data, len(dst), C.byref(size),
+                                     offsets.ctypes.data)
+        _check(st, "rcx_encode_blocks")
+        return int(size.value)
+
+    def decode_blocks_into(self, comp: np.ndarray, comp_size: int, offsets: np.ndarray, block: int, out: np.ndarray,
+                           coder: int = CODER_ADAPTIVE) -> int:
+        """rcx_decode_blocks with the caller's buffers -> decoded size."""
+        assert comp.dtype == np.uint8 and out.dtype == np.uint8 and offsets.dtype == np.uint64
+        assert comp.flags.c_contiguous and out.flags.c_contiguous and offsets.flags.c_contiguous
+        size = C.c_uint64()
+        st = lib().rcx_decode_blocks(self._h, coder, comp.ctypes.data, comp_size, offsets.ctypes.data, len(offsets) - 1, block,
+                                     out.ctypes.data, len(out), C.byref(size))
+        _check(st, "rcx_decode_blocks")
+        return int(size.value)
+
     def decode_blocks(self, payload, offsets, block: int, capacity: int | None = None, coder: int = CODER_ADAPTIVE):
         comp = _np_u8(payload)
         offs = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -244,6 +267,14 @@ class Context:
         _check(lib().rcx_bwt_decode(self._h, src.ctypes.data, len(src), dst.ctypes.data, len(dst) - 64, C.byref(size)), "rcx_bwt_decode")
         assert bool((dst[size.value:] == 0xA5).all()), "rcx_bwt_decode wrote past its size"
         return dst[: size.value]
+
+    def bwt_into(self, forward: bool, src: np.ndarray, dst: np.ndarray) -> int:
+        """rcx_bwt_encode / rcx_bwt_decode with the caller's buffers -> bytes written."""
+        assert src.dtype == np.uint8 and dst.dtype == np.uint8 and src.flags.c_contiguous and dst.flags.c_contiguous
+        size = C.c_uint64()
+        fn = lib().rcx_bwt_encode if forward else lib().rcx_bwt_decode
+        _check(fn(self._h, src.ctypes.data, len(src), dst.ctypes.data, len(dst), C.byref(size)), "rcx_bwt_encode" if forward else "rcx_bwt_decode")
+        return int(size.value)
 
     def bwt_encode_device(self, src, dst, stream=None) -> None:
         """src, dst: uint8 cuda tensors (dst >= bwt_encode_bound(src.numel())); enqueues only."""

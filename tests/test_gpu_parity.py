@@ -32,7 +32,7 @@ def gpu_encode(ctx, data, block, src_offset=0, coder=0):
     data = np.ascontiguousarray(data, dtype=np.uint8)
     n = len(data)
     buf = torch.zeros(n + src_offset + 16, dtype=torch.uint8, device="cuda")
-    buf[src_offset:src_offset + n] = torch.from_numpy(data).cuda()
+    buf[src_offset:src_offset + n] = torch.from_numpy(data.copy()).cuda()  # (a copy: the input may be a read-only view)
     src = buf[src_offset:src_offset + n]
     nblocks = rcx.block_count(n, block)
     dst = torch.zeros(rcx.encode_bound(n, block, coder), dtype=torch.uint8, device="cuda")
@@ -337,38 +337,51 @@ def test_single_stream_semantics(ctx, oracle, golden):
     assert hashlib.sha256(out[:1000]).hexdigest() == pins["decode_sink_full"]["out_sha256"]  # the fixture hashed the first 1000 bytes
 
 
-def test_full_size_properties(ctx, oracle):
-    """BASELINE config 2 at full size (1 GiB uniform, 64 KiB blocks): round trip, the size table, and a
-    sample of blocks byte-for-byte against the oracle (the whole GiB would take the CPU a minute)."""
+FULL_SIZE_RATIOS = {  # SURVEY.md section 8(d) / the reference build on these very bytes (profiles/r02_coder_soak.txt)
+    ("uniform", 0): 1.001814, ("canterbury", 0): 0.456671, ("zipf", 0): 0.779815,
+}
+
+
+@pytest.mark.parametrize("workload", ["uniform", "canterbury", "zipf"])
+def test_full_size_every_block(ctx, oracle, workload):
+    """BASELINE.json configs[1] (the std::mt19937(12345) GiB), configs[2] (the Canterbury GiB) and one shard of
+    configs[3] (the Zipf GiB of rank 0), 64 KiB blocks, at full size: EVERY one of the 16384 block streams byte for byte
+    against the oracle (all host threads), for the adaptive coder and once each for the static and the two rANS coders, plus
+    the round trip -- the reference harness's own every-byte compare (test/main.cpp:357-361) on BASELINE's own buffers."""
+    import os
     from cpprcoder_amd import rcx
     n, block = 1 << 30, 65536
     nblocks = n // block
-    g = torch.Generator(device="cuda")
-    g.manual_seed(12345)
-    src = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda", generator=g)
-    dst = torch.empty(rcx.encode_bound(n, block), dtype=torch.uint8, device="cuda")
-    offs = torch.zeros(nblocks + 1, dtype=torch.int64, device="cuda")
-    ctx.encode_blocks_device(src, block, dst, offs)
-    ctx.sync_status()
-    offsets = offs.cpu().numpy()
-    sizes = np.diff(offsets)
-    total = int(offsets[-1])
-    assert sizes.min() >= block and sizes.max() <= block + 200          # uniform bytes do not compress
-    assert abs(total / n - 1.00181) < 2e-4                                # SURVEY section 6.2 ratio @64 KiB
+    data = workloads.by_name(workload, n, 12345)
+    src = torch.from_numpy(data).cuda()
     out = torch.empty(n, dtype=torch.uint8, device="cuda")
-    ctx.decode_blocks_device(dst, total, offs, n, block, out)
-    ctx.sync_status()
-    assert torch.equal(out, src)
-    # every header says 65536 and every stream ends where the next begins
-    heads = dst[offs[:-1].unsqueeze(1) + torch.arange(4, device="cuda").unsqueeze(0)].cpu().numpy().astype(np.uint32)
-    assert np.all(heads[:, 0] + (heads[:, 1] << 8) + (heads[:, 2] << 16) + (heads[:, 3] << 24) == block)
-    rs = np.random.RandomState(1)
-    picks = sorted(set([0, 1, 63, 64, nblocks - 1] + [int(x) for x in rs.randint(0, nblocks, 123)]))
-    for b in picks:
-        blk = src[b * block:(b + 1) * block].cpu().numpy()
-        (st, _), ref, size = oracle.adaptive_encode(blk)
-        got = dst[int(offsets[b]): int(offsets[b + 1])].cpu().numpy().tobytes()
-        assert st == 0 and got == ref, f"block {b}"
+    offs = torch.zeros(nblocks + 1, dtype=torch.int64, device="cuda")
+    threads = min(os.cpu_count() or 16, 128)
+    for coder in (rcx.CODER_ADAPTIVE, rcx.CODER_STATIC, rcx.CODER_RANS, rcx.CODER_RANS8):
+        dst = torch.empty(rcx.encode_bound(n, block, coder), dtype=torch.uint8, device="cuda")
+        ctx.encode_blocks_device(src, block, dst, offs, coder=coder)
+        ctx.sync_status()
+        offsets = offs.cpu().numpy()
+        total = int(offsets[-1])
+        payload = dst[:total].cpu().numpy()
+        slots, sizes = oracle.encode_blocks(data, block, coder=coder, threads=threads)
+        assert np.array_equal(np.diff(offsets), sizes.astype(np.int64)), f"coder {coder}: per-block sizes differ from the oracle"
+        want, _ = oracle.compact(slots, sizes)
+        del slots
+        assert np.array_equal(payload, want), f"coder {coder}: block {int(np.searchsorted(offsets, int(np.argmax(payload != want)), side='right')) - 1} differs"
+        del want, payload
+        if (workload, coder) in FULL_SIZE_RATIOS:
+            assert abs(total / n - FULL_SIZE_RATIOS[(workload, coder)]) < 1e-6
+        out.zero_()
+        ctx.decode_blocks_device(dst, total, offs, n, block, out, coder=coder)
+        ctx.sync_status()
+        assert torch.equal(out, src), f"coder {coder}: round trip"
+        if coder in (rcx.CODER_ADAPTIVE, rcx.CODER_STATIC):
+            assert ctx.last_redo(nblocks) == 0  # (no block of a valid stream is left to the one-lane kernels)
+        if coder == rcx.CODER_ADAPTIVE:  # every header says 65536 and every stream ends where the next begins
+            heads = dst[offs[:-1].unsqueeze(1) + torch.arange(4, device="cuda").unsqueeze(0)].cpu().numpy().astype(np.uint32)
+            assert np.all(heads[:, 0] + (heads[:, 1] << 8) + (heads[:, 2] << 16) + (heads[:, 3] << 24) == block)
+        del dst
 
 
 # ---------------------------------------------------------------------------
