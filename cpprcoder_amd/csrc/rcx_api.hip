@@ -760,6 +760,7 @@ int rcx_decode_blocks(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
         *span = HostSpan{c->h_out + at, dst + at, (n - at < cb * block) ? n - at : cb * block};
         return RCX_OK;
     };
+    job.decode = true;
     r = host_run(c, p, job);
     const int latched = rcx_ctx_sync_status(c, nullptr, nullptr);
     if (r != RCX_OK) return r;

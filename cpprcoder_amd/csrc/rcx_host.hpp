@@ -21,9 +21,11 @@
 // * hipMemcpyAsync to PAGEABLE memory returns when the copy is done and keeps other threads' HIP calls waiting
 //   meanwhile (the first chunk's copy back stalled the feeder for 7 ms of a 30 ms call); from pageable memory it costs
 //   the feeder nothing comparable, and one feeder fills the link.  So by default pieces go in `direct` (the caller's
-//   memory handed to hipMemcpyAsync, pinned by the runtime on the fly) and come back `staged` (into one of two pinned
-//   slots per drainer, then memcpy by that drainer -- which is also what touches a fresh destination's pages, a few
-//   threads at once instead of one page fault at a time inside the runtime).  `register` (hipHostRegister on the
+//   memory handed to hipMemcpyAsync, pinned by the runtime on the fly); an encoder's output comes back `staged` (into
+//   one of two pinned slots per drainer, then memcpy by that drainer -- which is also what touches a fresh
+//   destination's pages, a few threads at once instead of one page fault at a time inside the runtime); a decoder's
+//   output, which only starts to come when the input is nearly in, comes back `direct` (three drainers' memcpy is
+//   slower than the link, and there the copy back is what is left at the end).  `register` (hipHostRegister on the
 //   caller's pieces first) is the third way; RCX_HOST_IN / RCX_HOST_OUT / RCX_HOST_MODE = direct | staged | register,
 //   RCX_HOST_FEEDERS / RCX_HOST_DRAINERS / RCX_HOST_MOVERS, RCX_HOST_PIECE_MIB and RCX_HOST_WORK_STREAMS override
 //   (tools/diag/host_sweep.sh; profiles/r03_host_rate.jsonl).
@@ -54,6 +56,7 @@ struct HostPipe {
     hipStream_t out_stream = nullptr;
     hipStream_t in_streams[RCX_HOST_MAX_MOVERS] = {};
     int in_mode = RCX_HOST_DIRECT, out_mode = RCX_HOST_STAGED;
+    int out_mode_decode = RCX_HOST_DIRECT; // (the decoders' output: see the top of the file)
     int feeders = 1, drainers = 3; // host threads per direction
     u64 piece = 16ull << 20; // bytes per copy
     u8* pin = nullptr;       // staged: two slots of `piece` bytes per feeder, then two per drainer
@@ -101,8 +104,10 @@ int host_pipe_get(rcx_ctx* c, HostPipe** out)
     };
     p->in_mode = mode_of(getenv("RCX_HOST_MODE"), p->in_mode);
     p->out_mode = mode_of(getenv("RCX_HOST_MODE"), p->out_mode);
+    p->out_mode_decode = mode_of(getenv("RCX_HOST_MODE"), p->out_mode_decode);
     p->in_mode = mode_of(getenv("RCX_HOST_IN"), p->in_mode);
     p->out_mode = mode_of(getenv("RCX_HOST_OUT"), p->out_mode);
+    p->out_mode_decode = mode_of(getenv("RCX_HOST_OUT"), p->out_mode_decode);
     auto count_of = [](const char* v, int otherwise) {
         const int m = v ? atoi(v) : 0;
         return m >= 1 && m <= RCX_HOST_MAX_MOVERS ? m : otherwise;
@@ -138,7 +143,8 @@ int host_pipe_words(HostPipe* p, u64 count)
 
 int host_pipe_pin(HostPipe* p)
 {
-    const u64 want = ((p->in_mode == RCX_HOST_STAGED ? 2ull * p->feeders : 0) + (p->out_mode == RCX_HOST_STAGED ? 2ull * p->drainers : 0)) * p->piece;
+    const bool out_staged = p->out_mode == RCX_HOST_STAGED || p->out_mode_decode == RCX_HOST_STAGED;
+    const u64 want = ((p->in_mode == RCX_HOST_STAGED ? 2ull * p->feeders : 0) + (out_staged ? 2ull * p->drainers : 0)) * p->piece;
     if (p->pin_bytes >= want) return RCX_OK;
     if (p->pin) (void)hipHostFree(p->pin);
     p->pin = nullptr;
@@ -163,6 +169,7 @@ struct HostJob {
     std::function<HostSpan(u64)> in;                 // caller's bytes -> device
     std::function<int(u64, hipStream_t)> launch;     // the chunk's kernels (+ small copies into HostPipe::words)
     std::function<int(u64, HostSpan*)> out;          // device -> caller's bytes; may return an error
+    bool decode = false;                             // the output is a decoder's (HostPipe::out_mode_decode)
 };
 
 struct HostRun {
@@ -275,7 +282,8 @@ void host_drainer(HostRun* r, int t)
 {
     HostPipe* p = r->p;
     if (hipSetDevice(r->c->device) != hipSuccess) return r->fail(RCX_E_HIP);
-    const bool staged = p->out_mode == RCX_HOST_STAGED;
+    const int out_mode = r->job->decode ? p->out_mode_decode : p->out_mode;
+    const bool staged = out_mode == RCX_HOST_STAGED;
     hipStream_t s = p->out_stream;
     u8* const mine = staged ? p->pin + ((p->in_mode == RCX_HOST_STAGED ? 2ull * p->feeders : 0) + 2ull * t) * p->piece : nullptr;
     u8* slot[2] = {mine, staged ? mine + p->piece : nullptr};
@@ -332,7 +340,7 @@ void host_drainer(HostRun* r, int t)
                 waiting = HostSpan{slot[into], span.to + at, len};
                 waiting_slot = into;
             } else {
-                if (p->out_mode == RCX_HOST_REGISTER) host_register(r, span.to + at, len);
+                if (out_mode == RCX_HOST_REGISTER) host_register(r, span.to + at, len);
                 ok = hipMemcpyAsync(span.to + at, span.from + at, len, hipMemcpyDeviceToHost, s) == hipSuccess;
             }
         }
