@@ -1220,15 +1220,13 @@ int rcx_bwt_reserve(rcx_ctx* c, uint64_t n)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcx_bwt_inv_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCX_BWT_INV_LDS));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcx_bwt_inv_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCX_BWT_INV_LDS));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcx_bwt_tie_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCX_BWT_TIE_LDS));
-        // The counting passes may rank with one LDS atomic per key if -- and only if -- this device returns the results
-        // of one ds_add_rtn_u32 in lane order (rcx_bwt.hpp): checked here, once per context.  RCX_BWT_MATCH=ballot|atomic
-        // overrides (tests run both).
+        // The counting passes rank the keys of a batch with ballots (documented behaviour only).  RCX_BWT_MATCH=atomic asks
+        // for one ds_add_rtn_u32 per key instead (5-25 % faster), which is only a stable rank if the LDS serves the lanes
+        // of one instruction in ascending lane order -- the ISA manual does not say so, so it is opt-in, and even then only
+        // taken if a short check on this device (rcx_bwt_lds_order_k, once per device and process) finds it to hold.
         const char* want = getenv("RCX_BWT_MATCH");
-        if (want && !strcmp(want, "ballot")) {
-            c->bwt_atomic = false;
-        } else if (want && !strcmp(want, "atomic")) {
-            c->bwt_atomic = true;
-        } else {
+        c->bwt_atomic = false;
+        if (want && !strcmp(want, "atomic")) {
             // (one answer per device and process: 0.3 ms the first time; a benign race if two threads ask at once)
             static int known[64]; // 0 = not asked, 1 = lane order holds, 2 = it does not
             int& answer = known[c->device & 63];

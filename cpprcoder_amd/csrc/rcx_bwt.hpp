@@ -69,8 +69,11 @@
 
 #define RCX_BWT_TIE_ROWS 0u
 #define RCX_BWT_TIE_WORD 65536u
-#define RCX_BWT_TIE_STACK (65536u + 16384u)
-#define RCX_BWT_TIE_LDS (RCX_BWT_TIE_STACK + RCX_TIE_STACK * 16u + 64u)
+#define RCX_BWT_TIE_RANK (65536u + 16384u)              /* u16 per class: its rotation's place (rank_classes) */
+#define RCX_BWT_TIE_HIST (RCX_BWT_TIE_RANK + 32768u)     /* 256 x 64 u16 counts of a counting pass / the next ranks */
+#define RCX_BWT_TIE_STACK (RCX_BWT_TIE_HIST + 32768u)
+#define RCX_BWT_TIE_SUMS (RCX_BWT_TIE_STACK + RCX_TIE_STACK * 16u)
+#define RCX_BWT_TIE_LDS (RCX_BWT_TIE_SUMS + 128u + 64u)
 
 // threadIdx.x as a value the compiler treats as new each time: what is computed from it (row numbers, list positions,
 // LDS addresses: one multiply-add each) is then computed where it is used.  Otherwise all of it is hoisted out of the
@@ -769,7 +772,8 @@ __global__ __launch_bounds__(1024) void rcx_bwt_fwd_k(const u8* __restrict__ src
 #endif
 }
 
-// Periodic blocks: the row index as the reference's sort leaves it.  One wave per listed block, lane 0 replays.
+// Periodic blocks: the row index as the reference's sort leaves it.  One wave per listed block; all its lanes run the
+// replay together (rcx_bwt_tie.hpp).
 __global__ __launch_bounds__(64) void rcx_bwt_tie_k(const u8* __restrict__ src, u8* __restrict__ dst, const u32* __restrict__ ties, u32* status)
 {
     extern __shared__ __attribute__((aligned(16))) u8 rcx_bwt_lds[];
@@ -782,11 +786,19 @@ __global__ __launch_bounds__(64) void rcx_bwt_tie_k(const u8* __restrict__ src, 
         const u64 b = ties[RCX_BWT_TIES_HEAD + 2 * i];
         const u32 p = ties[RCX_BWT_TIES_HEAD + 2 * i + 1];
         const u8* in = src + b * RCX_BWT_BLOCK;
-        for (u32 r = lane; r < RCX_BWT_BLOCK; r += 64) rows[r] = (uint16_t)r;
         for (u32 r = lane; r < p; r += 64) word[r] = in[r];
         __syncthreads();
         RcxTieSort t{rows, word, p - 1u, RCX_BWT_BLOCK};
-        if (lane == 0 && !t.run(stack)) rcx_flag(status, RCX_ST_CORRUPT, b); // (cannot happen: the stack bound)
+        // the classes' places among the rotations of the word first (the rows' space is free until then): less() is then
+        // one compare instead of a walk along two rows
+        uint16_t* rank = reinterpret_cast<uint16_t*>(rcx_bwt_lds + RCX_BWT_TIE_RANK);
+        uint16_t* hist = reinterpret_cast<uint16_t*>(rcx_bwt_lds + RCX_BWT_TIE_HIST);
+        t.rank_classes(rank, hist, rows, rows + 16384, hist, reinterpret_cast<uint16_t*>(rcx_bwt_lds + RCX_BWT_TIE_SUMS));
+        t.rank = rank;
+        for (u32 r = lane; r < RCX_BWT_BLOCK; r += 64) rows[r] = (uint16_t)r;
+        __syncthreads();
+        const bool done = t.run(stack);
+        if (lane == 0 && !done) rcx_flag(status, RCX_ST_CORRUPT, b); // (cannot happen: the stack bound)
         __syncthreads();
         for (u32 r = lane; r < RCX_BWT_BLOCK; r += 64)
             if (rows[r] == 0) {

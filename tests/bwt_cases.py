@@ -54,6 +54,11 @@ def cases() -> dict[str, np.ndarray]:
     c["period 8192, skewed bytes"] = _tile(np.minimum(mix(8192, 100), 40).astype(np.uint8))
     c["period 4096, ramp"] = _tile((np.arange(4096) // 16).astype(np.uint8))
     c["period 2048, sorted"] = _tile(np.sort(mix(2048, 6)))
+    # a period that is one long run and a single other byte: every partition pass of the reference's sort peels off two
+    # rows, so its replay makes thousands of passes over thousands of rows (the replay's worst case, csrc/rcx_bwt_tie.hpp)
+    c["period 16384, a run then b"] = _tile(np.concatenate([np.full(16383, 97, np.uint8), np.array([98], np.uint8)]))
+    c["period 4096, a run then b"] = _tile(np.concatenate([np.full(4095, 97, np.uint8), np.array([98], np.uint8)]))
+    c["period 8192, b then a run"] = _tile(np.concatenate([np.array([98], np.uint8), np.full(8191, 97, np.uint8)]))
     c["skewed bytes"] = np.minimum(mix(BLOCK, 101), 24).astype(np.uint8)   # not periodic, heapsort all the same
     # long runs of one byte (1 .. 4096 long): on the GPU such blocks start from run keys, not from two bytes
     c["long runs, two blocks"] = np.repeat(mix(64, 23), 1 + (mix(64, 24).astype(np.uint32) * 16 + mix(64, 25) % 16))[: 2 * BLOCK]

@@ -23,13 +23,22 @@ def sha(b) -> str:
     return hashlib.sha256(bytes(b)).hexdigest()
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=["ballot", "atomic"])
+def ctx(request):
+    """Every test of this file runs in both forms of the counting pass's rank (csrc/rcx_bwt.hpp): with ballots -- the
+    default, documented behaviour only -- and with one returning LDS atomic per key, which a caller opts into with
+    RCX_BWT_MATCH=atomic (read at the context's first block-sort call, so it stays set while the context lives)."""
     from cpprcoder_amd import rcx
     assert torch.cuda.is_available(), "GPU tests need a GPU"
+    before = os.environ.get("RCX_BWT_MATCH")
+    os.environ["RCX_BWT_MATCH"] = request.param
     c = rcx.Context(0)
     yield c
     c.close()
+    if before is None:
+        os.environ.pop("RCX_BWT_MATCH", None)
+    else:
+        os.environ["RCX_BWT_MATCH"] = before
 
 
 @pytest.fixture(scope="module")
