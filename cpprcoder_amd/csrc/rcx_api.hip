@@ -296,9 +296,14 @@ int rcx_ctx_create(int device, rcx_ctx** out)
     rcx_ctx* c = new (std::nothrow) rcx_ctx();
     if (!c) return RCX_E_NOMEM;
     c->device = device;
-    if (const char* v = getenv("RCX_LANES_PER_BLOCK")) c->lanes_per_block = (atoi(v) == 1 || atoi(v) == 4 || atoi(v) == 8) ? atoi(v) : 0;
+#if defined(RCX_WITH_VARIANTS) // (the diagnostic build with csrc/variants/: the superseded kernels can be chosen too)
+    const bool variants = true;
+#else
+    const bool variants = false;
+#endif
+    if (const char* v = getenv("RCX_LANES_PER_BLOCK")) c->lanes_per_block = (atoi(v) == 1 || atoi(v) == 4 || (variants && atoi(v) == 8)) ? atoi(v) : 0;
     if (const char* v = getenv("RCX_WIDE_WG")) c->wide_wg = atoi(v) ? 1 : 0;
-    if (const char* v = getenv("RCX_ENC_VARIANT")) c->enc_variant = atoi(v) >= 0 && atoi(v) <= 3 ? atoi(v) : 3;
+    if (const char* v = getenv("RCX_ENC_VARIANT")) c->enc_variant = (atoi(v) == 0 || atoi(v) == 3 || (variants && (atoi(v) == 1 || atoi(v) == 2))) ? atoi(v) : 3;
     if (const char* v = getenv("RCX_ENC_LANES")) c->enc_lanes = atoi(v) >= 1 && atoi(v) <= 64 ? atoi(v) : 0;
     if (const char* v = getenv("RCX_DEC_QUADS")) { const int q = atoi(v); c->dec_quads = (q == 1 || q == 2 || q == 4 || q == 8 || q == 16) ? q : 0; }
     {
@@ -455,6 +460,7 @@ int encode_range(rcx_ctx* c, int coder, const void* d_src, u64 n, u32 block, voi
             const u32 grid = (u32)((nblocks + lanes - 1) / lanes);
             hipLaunchKernelGGL(rcx_enc_mc5_k, dim3(grid), dim3(RCX_MC5_THREADS), 0, s, static_cast<const u8*>(d_src), n, block,
                                nblocks, v.slots, slot, v.sizes, c->divtab, c->status, v.redo, lanes);
+#if defined(RCX_WITH_VARIANTS)
         } else if (c->enc_variant == 2) {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_enc_mc_k, dim3(grid), dim3(RCX_MC_THREADS), 0, s, static_cast<const u8*>(d_src), n, block, nblocks,
@@ -463,6 +469,7 @@ int encode_range(rcx_ctx* c, int coder, const void* d_src, u64 n, u32 block, voi
             const u32 grid = (u32)((nblocks + RCX_OCT_BLOCKS - 1) / RCX_OCT_BLOCKS);
             hipLaunchKernelGGL(rcx_enc_oct_k, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block, nblocks,
                                v.slots, slot, v.sizes, c->divtab, c->status);
+#endif
         } else {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_enc_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_src), n, block,
@@ -577,6 +584,7 @@ int decode_range(rcx_ctx* c, int coder, const void* d_comp, u64 comp_size, const
                 hipLaunchKernelGGL(rcx_dec_quad_k<1>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks,
                                    block, n, static_cast<u8*>(d_dst), c->divtab, c->status, redo, quads);
             }
+#if defined(RCX_WITH_VARIANTS)
         } else if (decode_lanes(c, nblocks) == 8) {
             if (wide_workgroups(c, nblocks)) {
                 const u64 per_wg = RCX_OCT_BLOCKS * RCX_OCT_DEC_WAVES;
@@ -589,6 +597,7 @@ int decode_range(rcx_ctx* c, int coder, const void* d_comp, u64 comp_size, const
                 hipLaunchKernelGGL(rcx_dec_oct_k<1>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets, nblocks,
                                    block, n, static_cast<u8*>(d_dst), c->divtab, c->status);
             }
+#endif
         } else {
             const u32 grid = (u32)((nblocks + RCX_LANES - 1) / RCX_LANES);
             hipLaunchKernelGGL(rcx_dec_adaptive_k<false>, dim3(grid), dim3(64), 0, s, static_cast<const u8*>(d_comp), (u64)comp_size, d_offsets,
@@ -1063,10 +1072,12 @@ int rcx_stream_decode(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
 struct rcx_dstream {
     rcx_ctx* ctx = nullptr;
     RcxDState* state = nullptr; // device
-    u8* in = nullptr;           // device: every byte accepted so far
+    u8* in = nullptr;           // device: the bytes accepted so far that the decoder has not read yet (+ what it read since the last growth)
+    u64 in_base = 0;            // where in the stream in[0] is
     u64 in_bytes = 0, in_cap = 0;
+    u64 consumed = 0;           // how far the decoder has read (RcxDState::consumed)
     u8* out = nullptr;          // device: one launch's symbols
-    u32* result = nullptr;      // device: {made, finished, declared, produced}
+    u32* result = nullptr;      // device: {made, finished, declared, produced, consumed lo, consumed hi}
     u32* result_host = nullptr; // pinned
     bool finished = false;
     u32 declared = 0, produced = 0;
@@ -1083,8 +1094,8 @@ int rcx_dstream_create(rcx_ctx* c, rcx_dstream** out)
     d->ctx = c;
     if (hipMalloc(reinterpret_cast<void**>(&d->state), sizeof(RcxDState)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&d->out), RCX_DSTREAM_CHUNK) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d->result), 4 * sizeof(u32)) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&d->result_host), 4 * sizeof(u32), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d->result), 6 * sizeof(u32)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&d->result_host), 6 * sizeof(u32), hipHostMallocDefault) != hipSuccess ||
         hipMemset(d->state, 0, sizeof(RcxDState)) != hipSuccess) {
         rcx_dstream_destroy(d);
         return RCX_E_NOMEM;
@@ -1119,14 +1130,24 @@ int rcx_dstream_decode(rcx_dstream* d, const uint8_t* bytes, uint64_t size, uint
     }
     if (size) { // append
         if (d->in_bytes + size > d->in_cap) {
+            // More room: the new buffer takes only what the decoder has not read yet (it reads all it can, so that is a few
+            // bytes unless dst filled up first) -- the stream's past is dropped, and the decoder's memory stays at about twice
+            // the largest piece it was ever fed, not the size of the stream.
+            const u64 keep_from = d->consumed > d->in_base ? d->consumed - d->in_base : 0;
+            const u64 keep = d->in_bytes - keep_from;
             u64 cap = d->in_cap ? d->in_cap : (1u << 16);
-            while (cap < d->in_bytes + size) cap *= 2;
+            while (cap < keep + size) cap *= 2;
             u8* bigger = nullptr;
             if (hipMalloc(reinterpret_cast<void**>(&bigger), cap) != hipSuccess) return RCX_E_NOMEM;
-            if (d->in_bytes) HIP_TRY(hipMemcpy(bigger, d->in, d->in_bytes, hipMemcpyDeviceToDevice));
+            if (keep && hipMemcpy(bigger, d->in + keep_from, keep, hipMemcpyDeviceToDevice) != hipSuccess) {
+                (void)hipFree(bigger);
+                return RCX_E_HIP;
+            }
             if (d->in) (void)hipFree(d->in);
             d->in = bigger;
             d->in_cap = cap;
+            d->in_base += keep_from;
+            d->in_bytes = keep;
         }
         HIP_TRY(hipMemcpy(d->in + d->in_bytes, bytes, size, hipMemcpyHostToDevice));
         d->in_bytes += size;
@@ -1135,9 +1156,11 @@ int rcx_dstream_decode(rcx_dstream* d, const uint8_t* bytes, uint64_t size, uint
     for (;;) {
         const u64 room64 = dst_cap - made_total;
         const u32 room = room64 > RCX_DSTREAM_CHUNK ? RCX_DSTREAM_CHUNK : (u32)room64;
-        hipLaunchKernelGGL(rcx_dec_resume_k, dim3(1), dim3(64), 0, nullptr, d->state, d->in, d->in_bytes, d->out, room, d->result);
+        // (the kernel counts from the start of the stream: in[0] is byte in_base of it, and it never looks before what it has read)
+        hipLaunchKernelGGL(rcx_dec_resume_k, dim3(1), dim3(64), 0, nullptr, d->state, d->in - d->in_base, d->in_base + d->in_bytes, d->out, room, d->result);
         if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
-        HIP_TRY(hipMemcpy(d->result_host, d->result, 4 * sizeof(u32), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(d->result_host, d->result, 6 * sizeof(u32), hipMemcpyDeviceToHost));
+        d->consumed = (u64)d->result_host[4] | ((u64)d->result_host[5] << 32);
         const u32 made = d->result_host[0];
         d->finished = d->result_host[1] != 0;
         d->declared = d->result_host[2];

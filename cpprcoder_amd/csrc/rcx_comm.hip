@@ -24,7 +24,7 @@ struct rcx_comm {
     int nranks = 1;
     int rank = 0;
     ncclComm_t nccl = nullptr;
-    u64* d_mine = nullptr;   // {segment bytes, block count} of this rank
+    u64* d_mine = nullptr;   // what this rank brings and has room for: RCX_COMM_WORDS words (rcx_pack_sizes_k)
     u64* d_every = nullptr;  // the same of every rank
     u64* h_every = nullptr;  // pinned copy
 };
@@ -40,10 +40,17 @@ namespace
         if ((expr) != ncclSuccess) return RCX_E_COMM; \
     } while (0)
 
-__global__ void rcx_pack_sizes_k(const u64* __restrict__ offsets, u64 nblocks, u64* __restrict__ mine)
+// What a rank tells the others: {segment bytes, block count, room in its concat buffer, room in its table, table wanted}.
+// The capacities travel too, so that every rank judges the exchange by the SAME numbers (the smallest room anywhere) and
+// all of them refuse together -- a rank that stopped alone would leave its peers waiting in their receives.
+#define RCX_COMM_WORDS 5
+__global__ void rcx_pack_sizes_k(const u64* __restrict__ offsets, u64 nblocks, u64 concat_cap, u64 table_cap, u64 has_table, u64* __restrict__ mine)
 {
     mine[0] = offsets[nblocks]; // the encoder's exclusive prefix: offsets[nblocks] = segment bytes
     mine[1] = nblocks;
+    mine[2] = concat_cap;
+    mine[3] = table_cap;
+    mine[4] = has_table;
 }
 
 // this rank's part of the global table: local offsets shifted by the segment's base; the last rank also writes
@@ -103,9 +110,9 @@ int rcx_comm_create(int device, const void* id, int nranks, int rank, rcx_comm**
         rcx_comm_destroy(c);
         return RCX_E_COMM;
     }
-    if (hipMalloc(reinterpret_cast<void**>(&c->d_mine), 2 * sizeof(u64)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->d_every), 2 * sizeof(u64) * nranks) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&c->h_every), 2 * sizeof(u64) * nranks, hipHostMallocDefault) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void**>(&c->d_mine), RCX_COMM_WORDS * sizeof(u64)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_every), RCX_COMM_WORDS * sizeof(u64) * nranks) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&c->h_every), RCX_COMM_WORDS * sizeof(u64) * nranks, hipHostMallocDefault) != hipSuccess) {
         rcx_comm_destroy(c);
         return RCX_E_NOMEM;
     }
@@ -137,22 +144,29 @@ int rcx_allgatherv_segments(rcx_comm* c, const void* d_segment, const uint64_t* 
     const int n = c->nranks;
     // 1. what does every rank bring?  (the one host synchronisation of the exchange: send and receive counts are
     //    host arguments of the point-to-point calls)
-    hipLaunchKernelGGL(rcx_pack_sizes_k, dim3(1), dim3(1), 0, s, d_offsets, (u64)nblocks, c->d_mine);
-    NCCL_TRY(ncclAllGather(c->d_mine, c->d_every, 2, ncclUint64, c->nccl, s));
-    HIP_TRY(hipMemcpyAsync(c->h_every, c->d_every, 2 * sizeof(u64) * n, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(rcx_pack_sizes_k, dim3(1), dim3(1), 0, s, d_offsets, (u64)nblocks, (u64)concat_cap, (u64)table_cap, (u64)(d_table ? 1 : 0), c->d_mine);
+    NCCL_TRY(ncclAllGather(c->d_mine, c->d_every, RCX_COMM_WORDS, ncclUint64, c->nccl, s));
+    HIP_TRY(hipMemcpyAsync(c->h_every, c->d_every, RCX_COMM_WORDS * sizeof(u64) * n, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    // (four small host arrays and the synchronisation above per call: nothing next to a 17 ms step)
     std::vector<u64> seg(n), blk(n), seg_base(n + 1), block_base(n + 1);
+    u64 least_concat = ~0ull, least_table = ~0ull, tables = 0;
     for (int r = 0; r < n; ++r) {
-        seg[r] = c->h_every[2 * r];
-        blk[r] = c->h_every[2 * r + 1];
+        const u64* w = c->h_every + RCX_COMM_WORDS * r;
+        seg[r] = w[0];
+        blk[r] = w[1];
+        if (w[2] < least_concat) least_concat = w[2];
+        if (w[3] < least_table) least_table = w[3];
+        tables += w[4] ? 1 : 0;
     }
     int st = rcx_exchange_plan(seg.data(), blk.data(), n, seg_base.data(), block_base.data());
     if (st != RCX_OK) return st;
     if (seg_base_out) memcpy(seg_base_out, seg_base.data(), sizeof(u64) * (n + 1));
     if (block_base_out) memcpy(block_base_out, block_base.data(), sizeof(u64) * (n + 1));
-    // every rank sees the same plan: with equal capacities on all ranks they all stop here together
-    if (seg_base[n] > concat_cap) return RCX_E_CAPACITY;
-    if (d_table && block_base[n] + 1 > table_cap) return RCX_E_CAPACITY;
+    // every rank sees the same plan AND the same capacities: they all stop here together, before anything moves
+    if (tables != 0 && tables != (u64)n) return RCX_E_ARG; // some ranks want the table and some do not: unmatched messages
+    if (seg_base[n] > least_concat) return RCX_E_CAPACITY;
+    if (d_table && block_base[n] + 1 > least_table) return RCX_E_CAPACITY;
     // 2. own contribution in place
     u8* concat = static_cast<u8*>(d_concat);
     if (seg[c->rank]) HIP_TRY(hipMemcpyAsync(concat + seg_base[c->rank], d_segment, seg[c->rank], hipMemcpyDeviceToDevice, s));
@@ -164,18 +178,20 @@ int rcx_allgatherv_segments(rcx_comm* c, const void* d_segment, const uint64_t* 
     // 3. everybody else's, point to point, straight into place
     if (n > 1) {
         NCCL_TRY(ncclGroupStart());
-        for (int step = 1; step < n; ++step) {
+        bool ok = true; // (a call that fails inside the group still closes it)
+        for (int step = 1; step < n && ok; ++step) {
             const int to = (c->rank + step) % n, from = (c->rank - step + n) % n; // stagger the peers over the links
-            if (seg[c->rank]) NCCL_TRY(ncclSend(d_segment, seg[c->rank], ncclUint8, to, c->nccl, s));
-            if (seg[from]) NCCL_TRY(ncclRecv(concat + seg_base[from], seg[from], ncclUint8, from, c->nccl, s));
+            if (seg[c->rank]) ok = ok && ncclSend(d_segment, seg[c->rank], ncclUint8, to, c->nccl, s) == ncclSuccess;
+            if (seg[from]) ok = ok && ncclRecv(concat + seg_base[from], seg[from], ncclUint8, from, c->nccl, s) == ncclSuccess;
             if (d_table) {
                 // the table parts as shifted by their owners; the last rank's part carries the closing entry
                 const u64 mine = blk[c->rank] + (c->rank == n - 1 ? 1 : 0), theirs = blk[from] + (from == n - 1 ? 1 : 0);
-                if (mine) NCCL_TRY(ncclSend(d_table + block_base[c->rank], mine, ncclUint64, to, c->nccl, s));
-                if (theirs) NCCL_TRY(ncclRecv(d_table + block_base[from], theirs, ncclUint64, from, c->nccl, s));
+                if (mine) ok = ok && ncclSend(d_table + block_base[c->rank], mine, ncclUint64, to, c->nccl, s) == ncclSuccess;
+                if (theirs) ok = ok && ncclRecv(d_table + block_base[from], theirs, ncclUint64, from, c->nccl, s) == ncclSuccess;
             }
         }
-        NCCL_TRY(ncclGroupEnd());
+        const bool closed = ncclGroupEnd() == ncclSuccess;
+        if (!ok || !closed) return RCX_E_COMM;
     }
     return hipGetLastError() == hipSuccess ? RCX_OK : RCX_E_HIP;
 }

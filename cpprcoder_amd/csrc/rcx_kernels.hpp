@@ -387,10 +387,14 @@ __global__ __launch_bounds__(64) void rcx_dec_resume_k(RcxDState* __restrict__ s
     result[1] = produced >= want ? 1u : 0u; // finished
     result[2] = declared;
     result[3] = produced;
+    result[4] = (u32)consumed; // how far into the stream the decoder has read: the host drops what lies before
+    result[5] = (u32)(consumed >> 32);
 }
 
 #include "rcx_oct.hpp"
+#if defined(RCX_WITH_VARIANTS) // superseded kernels, kept for comparison: only in the diagnostic build (build.py build_variants)
 #include "variants/rcx_variants.hpp"
+#endif
 #include "rcx_static.hpp"
 #include "rcx_rans.hpp"
 #include "rcx_bwt.hpp"

@@ -43,14 +43,20 @@ def allgatherv_p2p(segment: torch.Tensor, offsets: torch.Tensor, concat: torch.T
     Every rank raises together if a buffer is too small (the plan is the same everywhere)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     nblocks = offsets.numel() - 1
-    mine = torch.stack([offsets[-1].to(torch.int64), torch.tensor(nblocks, dtype=torch.int64, device=offsets.device)])
-    every = torch.zeros(2 * world, dtype=torch.int64, device=offsets.device)
+    # {segment bytes, blocks, room in concat, room in the table, table wanted}: the capacities travel with the sizes, so every
+    # rank judges by the smallest room ANY rank has and they all refuse together (csrc/rcx_comm.hip does the same)
+    words = [int(offsets[-1]), nblocks, concat.numel(), table.numel() if table is not None else 0, 1 if table is not None else 0]
+    mine = torch.tensor(words, dtype=torch.int64, device=offsets.device)
+    every = torch.zeros(5 * world, dtype=torch.int64, device=offsets.device)
     dist.all_gather_into_tensor(every, mine, group=group)
-    every = every.cpu().view(world, 2)
+    every = every.cpu().view(world, 5)
     seg, blk = [int(x) for x in every[:, 0]], [int(x) for x in every[:, 1]]
     seg_base, block_base = exchange_plan(seg, blk)
-    if seg_base[-1] > concat.numel() or (table is not None and block_base[-1] + 1 > table.numel()):
-        raise ValueError("concat / table too small for the gathered segments")
+    wanted = int(every[:, 4].sum())
+    if wanted not in (0, world):
+        raise ValueError("some ranks pass a table and some do not")
+    if seg_base[-1] > int(every[:, 2].min()) or (table is not None and block_base[-1] + 1 > int(every[:, 3].min())):
+        raise ValueError("concat / table too small for the gathered segments on some rank")
     concat[seg_base[rank]: seg_base[rank] + seg[rank]].copy_(segment[: seg[rank]])
     if table is not None:
         table[block_base[rank]: block_base[rank] + nblocks].copy_(offsets[:nblocks] + seg_base[rank])

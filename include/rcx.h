@@ -174,6 +174,8 @@ int rcx_stream_decode(rcx_ctx* ctx, int coder, const uint8_t* comp, uint64_t com
  *       far: the input ran dry (cpprcoder.h:901-903) or dst is full (call again with size 0 to go on -- unlike the
  *       reference, whose sink-full return has already swallowed a symbol, cpprcoder.h:909-911).  A first call with
  *       fewer than 8 bytes keeps nothing and asks for 8 (cpprcoder.h:877-880).
+ *   Memory: the object keeps, on the device, the bytes it was fed and has not read yet; what it has read is dropped when its
+ *   buffer grows, so it holds about twice the largest piece it was ever given, whatever the length of the stream.
  */
 typedef struct rcx_dstream rcx_dstream;
 int rcx_dstream_create(rcx_ctx* ctx, rcx_dstream** out);
@@ -228,7 +230,10 @@ int rcx_bwt_last_ties(rcx_ctx* ctx, uint64_t* count);
  *       d_concat (concat_cap bytes)        receives every rank's segment back to back, rank 0 first
  *       d_table (table_cap entries, or NULL)  receives the table of the concatenation: sum(nblocks)+1 offsets into d_concat
  *       seg_base_out / block_base_out      optional host arrays of nranks+1: where rank r's bytes / blocks start
- *     Every rank must pass the same capacities: then RCX_E_CAPACITY is returned by all of them, before anything moves.
+ *     The capacities and whether a table is wanted travel with the sizes: every rank judges by the smallest room any rank
+ *     has, so RCX_E_CAPACITY -- or RCX_E_ARG if only some ranks pass a table -- is returned by ALL ranks, before anything moves.
+ *     (Two or more ranks over RCCL have not run on hardware yet: the 1-GPU box runs one rank, tests/test_gpu_comm.py; the
+ *     logic for more is checked on gloo, tests/test_parallel_gloo.py.)
  */
 #define RCX_COMM_ID_BYTES 128
 typedef struct rcx_comm rcx_comm;

@@ -54,6 +54,12 @@ def _worker(rank: int, world: int, port: int, ret):
             parallel.allgatherv_p2p(seg, torch.from_numpy(offsets.astype(np.int64)), concat[: total - 1], table)
         with pytest.raises(ValueError):
             parallel.allgatherv_p2p(seg, torch.from_numpy(offsets.astype(np.int64)), concat, table[:nblocks])
+        # ... also when only ONE rank's buffer is too small (the capacities travel with the sizes), or only one wants a table:
+        # a rank that stopped alone would leave the others waiting in their receives
+        with pytest.raises(ValueError):
+            parallel.allgatherv_p2p(seg, torch.from_numpy(offsets.astype(np.int64)), concat[: total - 1] if rank == 1 else concat, table)
+        with pytest.raises(ValueError):
+            parallel.allgatherv_p2p(seg, torch.from_numpy(offsets.astype(np.int64)), concat, table if rank == 0 else None)
         # every rank can now decode the WHOLE buffer from the concatenated stream
         stream = concat[:total].numpy()
         tbl = table.numpy().astype(np.uint64)

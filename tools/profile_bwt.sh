@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX (gpurun -- 'bash tools/profile_bwt.sh r02_bwt'): rocprofv3 passes over the block sort
 # (tools/bwt_rate.py: forward + inverse of 1 GiB per workload).  Kernel trace + stats in one pass, each PMC group in its
-# own pass (--pmc is never combined with other trace domains).  Then
+# own pass (every --pmc pass carries --kernel-trace and nothing else: no sys / runtime / hip / hsa / memory-copy / marker trace next to counters).  Then
 #   python profiles/summarize.py <tag> gpurun_out/<tag>_stats --side --config workload=canterbury,bytes=1073741824,block=32768 --pmc fetch=... write=... sq1=... sq2=...
 set -e -o pipefail
 TAG=${1:-r02_bwt}

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX (gpurun -- 'bash tools/profile_round.sh r02'): the rocprofv3 passes bench.py's roofline block and
 # profiles/ are built from.  Kernel trace + stats in one pass, each PMC group in its own pass (FETCH_SIZE and WRITE_SIZE
-# do not fit the TCC slots together; --pmc is never combined with other trace domains).  Outputs under gpurun_out/<tag>_*;
+# do not fit the TCC slots together; every --pmc pass carries --kernel-trace and nothing else: no sys / runtime / hip / hsa / memory-copy / marker trace next to counters).  Outputs under gpurun_out/<tag>_*;
 # `python profiles/summarize.py <tag> gpurun_out/<tag>_stats --pmc ...` then turns them into profiles/<tag>_*.
 set -e -o pipefail
 TAG=${1:-r02}
