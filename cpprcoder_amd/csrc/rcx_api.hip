@@ -42,6 +42,7 @@ struct rcx_ctx {
     int dec_quads = 0;       // blocks per quad-decoder wave: 0 = from the block count, else 1, 2, 4, 8, 16 (RCX_DEC_QUADS)
     int cus = 256;           // compute units of the device
     bool rans1_lds_set = false; // rcx_enc_rans1_k has been allowed its 128 KiB of dynamic LDS
+    bool rans1w_lds_set = false; // the same for rcx_enc_rans1w_k
     bool rans_track = false; // the single-stream rANS decode wants the payload bytes consumed (status[2])
     // scratch
     u8* slots = nullptr;
@@ -430,21 +431,37 @@ int encode_range(rcx_ctx* c, int coder, const void* d_src, u64 n, u32 block, voi
                 // one state per block = one chain per block: the model by octets, then the coding loop one lane per
                 // block, `lanes` blocks per wave so that every SIMD has a wave before any wave carries 64
                 hipLaunchKernelGGL(rcx_rans_model_k<14>, dim3(grid), dim3(256), 0, s, static_cast<const u8*>(d_src), n, block, nblocks, v.models);
-                // 16 blocks per wave, four waves per workgroup, 2 KiB of LDS per block: 128 KiB = one workgroup per CU.
-                // Measured (profiles/r02_sweep_rans.jsonl, RCX_RANS1_LANES): thinner waves on more CUs are SLOWER here
-                // (4096 blocks of 256 KiB: 34 ms with 16 lanes on 64 CUs, 99 ms with 4 lanes on 256 CUs).
-                u32 lanes = 16;
-                if (const char* v = getenv("RCX_RANS1_LANES")) { const int q = atoi(v); if (q == 1 || q == 2 || q == 4 || q == 8 || q == 16) lanes = (u32)q; }
-                const u64 per_wg1 = (u64)lanes * RCX_RANS1_ENC_WAVES;
-                const u32 grid1 = (u32)((nblocks + per_wg1 - 1) / per_wg1);
-                const u32 lds_bytes = lanes * RCX_RANS1_ENC_WAVES * 2048u;
-                if (!c->rans1_lds_set) { // more than the 64 KiB a kernel gets without asking
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rcx_enc_rans1_k), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
-                        return RCX_E_HIP;
-                    c->rans1_lds_set = true;
+                // The coding loop: two waves per 64 blocks (coder, writer), 2 KiB of table per block: one workgroup per CU.
+                // RCX_RANS1_WAVES=1 (diagnostic): the one-wave kernel it replaced, 16 blocks per wave (RCX_RANS1_LANES),
+                // four waves per workgroup.
+                const char* one = getenv("RCX_RANS1_WAVES");
+                if (!(one && atoi(one) == 1)) {
+                    if (!c->rans1w_lds_set) { // more than the 64 KiB a kernel gets without asking
+                        if (hipFuncSetAttribute(reinterpret_cast<const void*>(rcx_enc_rans1w_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCX_R1W_LDS_BYTES) != hipSuccess)
+                            return RCX_E_HIP;
+                        c->rans1w_lds_set = true;
+                    }
+                    hipLaunchKernelGGL(rcx_enc_rans1w_k, dim3((u32)((nblocks + 63) / 64)), dim3(128), RCX_R1W_LDS_BYTES, s, static_cast<const u8*>(d_src), n, block,
+                                       nblocks, static_cast<const u32*>(v.models), v.slots, slot, v.sizes, v.starts, c->status);
+                } else {
+                    u32 lanes = 16;
+                    if (const char* v2 = getenv("RCX_RANS1_LANES")) { const int q = atoi(v2); if (q == 1 || q == 2 || q == 4 || q == 8 || q == 16) lanes = (u32)q; }
+                    const u64 per_wg1 = (u64)lanes * RCX_RANS1_ENC_WAVES;
+                    const u32 grid1 = (u32)((nblocks + per_wg1 - 1) / per_wg1);
+                    u32 lds_bytes = lanes * RCX_RANS1_ENC_WAVES * 2048u;
+                    // RCX_RANS1_ALONE=1 (diagnostic): more LDS than two workgroups have room for, so that thin workgroups are not
+                    // stacked on one CU
+                    if (getenv("RCX_RANS1_ALONE") && lds_bytes < 84u * 1024u) lds_bytes = 84u * 1024u;
+                    u32 lanes_shift = 0;
+                    while ((1u << lanes_shift) < lanes) ++lanes_shift;
+                    if (!c->rans1_lds_set) {
+                        if (hipFuncSetAttribute(reinterpret_cast<const void*>(rcx_enc_rans1_k), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+                            return RCX_E_HIP;
+                        c->rans1_lds_set = true;
+                    }
+                    hipLaunchKernelGGL(rcx_enc_rans1_k, dim3(grid1), dim3(64 * RCX_RANS1_ENC_WAVES), lds_bytes, s, static_cast<const u8*>(d_src), n, block,
+                                       nblocks, static_cast<const u32*>(v.models), v.slots, slot, v.sizes, v.starts, c->status, lanes_shift);
                 }
-                hipLaunchKernelGGL(rcx_enc_rans1_k, dim3(grid1), dim3(64 * RCX_RANS1_ENC_WAVES), lds_bytes, s, static_cast<const u8*>(d_src), n, block,
-                                   nblocks, static_cast<const u32*>(v.models), v.slots, slot, v.sizes, v.starts, c->status, lanes);
             }
         } else if (static3) {
             const u32 lanes = rg.packed ? RCX_LANES : encode_lanes(c, nblocks);

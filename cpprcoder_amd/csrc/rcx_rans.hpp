@@ -584,8 +584,8 @@ __global__ __launch_bounds__(256) void rcx_rans_model_k(const u8* __restrict__ s
     }
 }
 
-// One lane per block; `lanes_used` of the wave's 64 lanes carry a block (see rcx_api.hip: every SIMD gets a wave before
-// any wave carries 64).  LDS (dynamic, 2 KiB per lane in use): entry s of lane l at 8 * (s * lanes_used + l).
+// One lane per block; `lanes_used` = 1 << lanes_shift of the wave's 64 lanes carry a block.  LDS (dynamic, 2 KiB per lane
+// in use): entry s of lane l at 8 * (s * lanes_used + l) -- a shift, not a multiplication: the index is formed per symbol.
 struct alignas(8) RcxRansSym {
     u32 rcp, packed; // see rcx_rans_model_k
 };
@@ -594,9 +594,10 @@ struct alignas(8) RcxRansSym {
 __global__ __launch_bounds__(64 * RCX_RANS1_ENC_WAVES) void rcx_enc_rans1_k(const u8* __restrict__ src, u64 n, u32 block, u64 nblocks,
                                                                            const u32* __restrict__ models, u8* __restrict__ slots, u64 slot,
                                                                            u32* __restrict__ sizes, u32* __restrict__ starts, u32* status,
-                                                                           u32 lanes_used)
+                                                                           u32 lanes_shift)
 {
     extern __shared__ RcxRansSym rcx_rans1_lds[];
+    const u32 lanes_used = 1u << lanes_shift;
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const bool in_use = lane < lanes_used;
     const u64 blk = in_use ? ((u64)blockIdx.x * RCX_RANS1_ENC_WAVES + wave) * lanes_used + lane : nblocks;
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(64 * RCX_RANS1_ENC_WAVES) void rcx_enc_rans1_k(cons
     RcxRansSym* table = rcx_rans1_lds + wave * 256u * lanes_used + (in_use ? lane : 0u);
     if (live) {
         const RcxRansSym* m = reinterpret_cast<const RcxRansSym*>(models + blk * RCX_RANS_MODEL_DW + 264);
-        for (u32 sy = 0; sy < 256; ++sy) table[sy * lanes_used] = m[sy];
+        for (u32 sy = 0; sy < 256; ++sy) table[sy << lanes_shift] = m[sy];
     }
     const u8* in = src + at;
     u8* const slot_base = slots + (live ? blk : 0) * slot;
@@ -651,12 +652,12 @@ __global__ __launch_bounds__(64 * RCX_RANS1_ENC_WAVES) void rcx_enc_rans1_k(cons
         const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
         while (i != 0 && (!aligned || (i & 15u) != 0)) { // the ragged end (and everything, if the block is not aligned)
             --i;
-            const RcxRansSym e = table[(u32)in[i] * lanes_used];
+            const RcxRansSym e = table[(u32)in[i] << lanes_shift];
             RCX_RANS1_PUT(e);
         }
         if (i != 0) {
             U4 cur = *reinterpret_cast<const U4*>(in + i - 16);
-            RcxRansSym e_next = table[rcx_byte_of(cur, 15) * lanes_used];
+            RcxRansSym e_next = table[rcx_byte_of(cur, 15) << lanes_shift];
             while (i != 0) {
                 i -= 16;
                 U4 nxt = cur;
@@ -664,7 +665,7 @@ __global__ __launch_bounds__(64 * RCX_RANS1_ENC_WAVES) void rcx_enc_rans1_k(cons
 #pragma unroll
                 for (u32 k = 16; k-- > 0;) {
                     const RcxRansSym e = e_next; // the next symbol's constants are on their way while this one is coded
-                    e_next = table[(k != 0 ? rcx_byte_of(cur, k - 1) : rcx_byte_of(nxt, 15)) * lanes_used];
+                    e_next = table[(k != 0 ? rcx_byte_of(cur, k - 1) : rcx_byte_of(nxt, 15)) << lanes_shift];
                     RCX_RANS1_PUT(e);
                 }
                 cur = nxt;
@@ -689,6 +690,183 @@ __global__ __launch_bounds__(64 * RCX_RANS1_ENC_WAVES) void rcx_enc_rans1_k(cons
         if (overflow) rcx_flag(status, RCX_ST_CAPACITY, blk);
     }
 #undef RCX_RANS1_PUT
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The same encoder as two waves per 64 blocks (default): what one symbol costs a lone wave is the number of instructions
+// it issues (rcx_enc_rans1_k: 49 vector + 7 other instructions a symbol = 311 cycles, profiles/r03_rans1_pmc.json), and
+// half of them only move bytes.  So the work is cut where rANS allows it -- the state never needs anything back from the
+// bytes it has put out (no carry, unlike the range coder):
+//   wave 0, the coder:  table lookup (one symbol ahead), the renormalisation test, x = C(s, x); per symbol it hands over
+//                       one word: the 0..2 bytes that leave, in the order they go to memory, and how many;
+//   wave 1, the writer: gathers the bytes into dwords (a 64-bit register, the four oldest leave), puts the dwords into
+//                       a 64-byte ring per block in LDS and, once per chunk of 16 symbols, stores what has become whole
+//                       16-byte pieces, backwards from the end of the slot (no store, and no branch, per symbol).
+// They meet once per chunk (LDS records, double-buffered; s_waitcnt lgkmcnt(0) + s_barrier).  LDS: 128 KiB of tables
+// (2 KiB a block, as before) + 8 KiB of records + 4 KiB of rings: one workgroup of 64 blocks per CU, 256 for a GiB.
+// Measured (1 GiB of Zipf bytes, 64 KiB blocks): 8.49 -> 5.71 ms; each wave issues about 27 instructions a symbol at
+// about 7 cycles each (the two land on different SIMDs: an idle wave between them changes nothing).
+// ---------------------------------------------------------------------------------------------------------
+#define RCX_R1W_CHUNK 16u
+#define RCX_R1W_RING_WORDS 16u /* a chunk makes at most 8 words and at most 3 stay behind after a drain */
+#define RCX_R1W_TABLE_BYTES (256u * 64u * 8u)
+#define RCX_R1W_REC_DW (2u * RCX_R1W_CHUNK * 64u)
+#define RCX_R1W_LDS_BYTES (RCX_R1W_TABLE_BYTES + 4u * RCX_R1W_REC_DW + 4u * (RCX_R1W_RING_WORDS + 1u) * 64u + 4u * 64u)
+
+template <bool FULL>
+__device__ __forceinline__ void rcx_rans1w_pipeline(u32 wave, u32 lane, bool live, u32 len, u32 nchunks, const u8* in, const RcxRansSym* table,
+                                                    u32* rec, u32* oring, u8* slot_base, u32 slot, u32& x, u64& acc, u32& nacc, u32& words, u32& drained,
+                                                    bool& overflow)
+{
+    const u32 max_words = (slot - (RCX_RANS_HEADER + 8u)) >> 2; // (the tail -- held bytes, state, header -- has its room below)
+    // the coder's look-ahead: the 16 bytes of the chunk it is about to code, and the first symbol's constants
+    U4 cur, nxt;
+    cur.x = cur.y = cur.z = cur.w = 0;
+    nxt = cur;
+    RcxRansSym e_next;
+    e_next.rcp = 0xFFFFFFFFu;
+    e_next.packed = 16383u; // (freq 1, start 0: harmless for a lane that codes nothing)
+    auto byte_at = [&](u32 i) -> u32 { return (live && i < len) ? (u32)in[i] : 0u; };
+    if (wave == 0 && nchunks != 0) {
+        const u32 i0 = (nchunks - 1) * RCX_R1W_CHUNK;
+        if (FULL) cur = *reinterpret_cast<const U4*>(in + i0);
+        if (FULL && nchunks > 1) nxt = *reinterpret_cast<const U4*>(in + i0 - RCX_R1W_CHUNK);
+        e_next = table[(FULL ? rcx_byte_of(cur, 15) : byte_at(i0 + 15)) * 64u];
+    }
+    for (u32 k = 0; k <= nchunks; ++k) {
+        if (wave == 0) {
+            if (k < nchunks) { // ---- the coder: chunk c, its symbols from the last to the first ----
+                const u32 c = nchunks - 1 - k;
+                const u32 i0 = c * RCX_R1W_CHUNK;
+                u32* out = rec + (k & 1u) * (RCX_R1W_CHUNK * 64u) + lane;
+                U4 ahead = nxt; // the chunk after the next
+                if (FULL && c >= 2) ahead = *reinterpret_cast<const U4*>(in + i0 - 2 * RCX_R1W_CHUNK);
+#pragma unroll
+                for (u32 t = 0; t < RCX_R1W_CHUNK; ++t) {
+                    const u32 s = RCX_R1W_CHUNK - 1 - t;
+                    const RcxRansSym e = e_next; // the next symbol's constants are on their way while this one is coded
+                    {
+                        u32 b;
+                        if (FULL) b = s != 0 ? rcx_byte_of(cur, s - 1) : rcx_byte_of(nxt, 15);
+                        else b = (i0 + s) != 0 ? byte_at(i0 + s - 1) : 0u;
+                        e_next = table[b * 64u];
+                    }
+                    // cppans.h:265-287 with the reference's EncSymbol constants (see rcx_rans_model_k)
+                    const u32 cmpl = e.packed & 0x3FFFu, shift = (e.packed >> 14) & 15u, start = e.packed >> 18;
+                    const u32 x_max = (16384u - cmpl) << 17;
+                    const u32 n_out = (x_max <= x ? 1u : 0u) + (x_max <= (x >> 8) ? 1u : 0u); // bytes leaving: x & 0xFF, then (x >> 8) & 0xFF
+                    const u32 two = ((x & 0xFFu) << 8) | ((x >> 8) & 0xFFu);                    // (the later one ends up lower in memory)
+                    const u32 bytes = n_out == 2 ? two : (n_out == 1 ? (x & 0xFFu) : 0u);
+                    const bool on = FULL || (live && i0 + s < len);
+                    out[t * 64u] = on ? (bytes | (n_out << 16)) : 0u;
+                    const u32 xs = x >> (8 * n_out);
+                    const u32 q = __umulhi(xs, e.rcp) >> shift;
+                    const u32 bias = start + (cmpl == 16383u ? 16383u : 0u); // freq = 1: cppans.h:232-234
+                    x = on ? xs + bias + rcx_mul24(q, cmpl) : x;
+                }
+                cur = nxt;
+                nxt = ahead;
+            }
+        } else if (k >= 1) { // ---- the writer: the records of the step before ----
+            const u32* rs = rec + ((k - 1) & 1u) * (RCX_R1W_CHUNK * 64u) + lane;
+            u32* ring = oring + lane;
+            u32* dummy = oring + RCX_R1W_RING_WORDS * 64u + lane;
+            u32 r_next = rs[0];
+#pragma unroll
+            for (u32 t = 0; t < RCX_R1W_CHUNK; ++t) {
+                const u32 r = r_next;
+                if (t + 1 < RCX_R1W_CHUNK) r_next = rs[(t + 1) * 64u];
+                const u32 sh = (r >> 13) & 24u; // 8 x the count
+                acc = (acc << sh) | (u64)(r & 0xFFFFu);
+                nacc += r >> 16;
+                // with 4 or 5 bytes held the four oldest leave as one dword
+                const bool due = nacc >= 4;
+                const u32 keep8 = (8 * nacc) & 8u; // 8 x (nacc - 4) when due: 0 or 8
+                const u32 word = (u32)(acc >> keep8);
+                const bool room = words < max_words;
+                overflow = overflow || (due && !room);
+                const bool put = due && room;
+                u32* where = put ? ring + (words % RCX_R1W_RING_WORDS) * 64u : dummy;
+                *where = word;
+                words += put ? 1u : 0u;
+                acc = due ? (acc & ((1ull << keep8) - 1ull)) : acc;
+                nacc -= due ? 4u : 0u;
+            }
+            // whole 16-byte pieces go to memory: words d .. d+3 lie at slot - 4 (d + 4), the newest lowest
+            while (__any(live && drained + 4 <= words)) {
+                if (live && drained + 4 <= words) {
+                    U4 piece;
+                    piece.x = ring[((drained + 3) % RCX_R1W_RING_WORDS) * 64u];
+                    piece.y = ring[((drained + 2) % RCX_R1W_RING_WORDS) * 64u];
+                    piece.z = ring[((drained + 1) % RCX_R1W_RING_WORDS) * 64u];
+                    piece.w = ring[((drained + 0) % RCX_R1W_RING_WORDS) * 64u];
+                    *reinterpret_cast<U4*>(slot_base + slot - 4u * (drained + 4u)) = piece;
+                    drained += 4;
+                }
+            }
+        }
+        rcx_lds_barrier();
+    }
+}
+
+__global__ __launch_bounds__(128) void rcx_enc_rans1w_k(const u8* __restrict__ src, u64 n, u32 block, u64 nblocks, const u32* __restrict__ models,
+                                                        u8* __restrict__ slots, u64 slot, u32* __restrict__ sizes, u32* __restrict__ starts,
+                                                        u32* status)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 rcx_r1w_lds[];
+    RcxRansSym* table_all = reinterpret_cast<RcxRansSym*>(rcx_r1w_lds);
+    u32* rec = reinterpret_cast<u32*>(rcx_r1w_lds + RCX_R1W_TABLE_BYTES);
+    u32* oring = rec + RCX_R1W_REC_DW;
+    u32* final_x = oring + (RCX_R1W_RING_WORDS + 1u) * 64u;
+    const u32 lane = threadIdx.x & 63u;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u64 blk = (u64)blockIdx.x * 64u + lane;
+    const bool live = blk < nblocks;
+    const u64 at = live ? blk * (u64)block : 0;
+    const u32 len = live ? (u32)((n - at) < (u64)block ? (n - at) : (u64)block) : 0u;
+    const u8* in = src + at;
+    RcxRansSym* table = table_all + lane; // entry s at table[64 s]
+    if (live) {
+        const RcxRansSym* m = reinterpret_cast<const RcxRansSym*>(models + blk * RCX_RANS_MODEL_DW + 264);
+        for (u32 sy = wave; sy < 256; sy += 2) table[sy * 64u] = m[sy];
+    }
+    const u32 maxlen = rcx_wave_max(len);
+    const bool full = __all(live && len == block) && (block % 16u == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+    const u32 nchunks = (maxlen + RCX_R1W_CHUNK - 1) / RCX_R1W_CHUNK;
+    rcx_lds_barrier();
+
+    u8* const slot_base = slots + (live ? blk : 0) * slot;
+    u32 x = 1u << 23; // cppans.h:260-263
+    u64 acc = 0;      // bytes not yet in a dword, the newest lowest
+    u32 nacc = 0, words = 0, drained = 0;
+    bool overflow = false;
+    if (full) rcx_rans1w_pipeline<true>(wave, lane, live, len, nchunks, in, table, rec, oring, slot_base, (u32)slot, x, acc, nacc, words, drained, overflow);
+    else rcx_rans1w_pipeline<false>(wave, lane, live, len, nchunks, in, table, rec, oring, slot_base, (u32)slot, x, acc, nacc, words, drained, overflow);
+    if (wave == 0) final_x[lane] = x;
+    rcx_lds_barrier();
+    if (wave == 1 && live) {
+        // what the ring still holds, the bytes still held, the state (cppans.h:289-299), the header (:521-527)
+        const u32* ring = oring + lane;
+        for (u32 d = drained; d < words; ++d) *reinterpret_cast<u32*>(slot_base + slot - 4u * (d + 1u)) = ring[(d % RCX_R1W_RING_WORDS) * 64u];
+        u32 ptr = (u32)slot - 4u * words;
+        for (u32 k = nacc; k-- > 0;) { // oldest first: it sits highest
+            ptr -= 1;
+            slot_base[ptr] = (u8)(acc >> (8 * k));
+        }
+        const u32 xf = final_x[lane];
+        ptr -= 4;
+        slot_base[ptr] = (u8)xf, slot_base[ptr + 1] = (u8)(xf >> 8), slot_base[ptr + 2] = (u8)(xf >> 16), slot_base[ptr + 3] = (u8)(xf >> 24);
+        ptr -= RCX_RANS_HEADER;
+        const u32* cum = models + blk * RCX_RANS_MODEL_DW;
+        u8* h = slot_base + ptr;
+        for (u32 w = 0; w < 258; ++w) {
+            const u32 v = w == 0 ? len : cum[w - 1];
+            h[4 * w] = (u8)v, h[4 * w + 1] = (u8)(v >> 8), h[4 * w + 2] = (u8)(v >> 16), h[4 * w + 3] = (u8)(v >> 24);
+        }
+        sizes[blk] = overflow ? 0u : (u32)slot - ptr;
+        starts[blk] = overflow ? 0u : ptr;
+        if (overflow) rcx_flag(status, RCX_ST_CAPACITY, blk);
+    }
 }
 
 // Decode, 4 lanes per block.  LDS per wave: four table groups (rcx_oct.hpp: node n of the four blocks of a group in

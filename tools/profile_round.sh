@@ -4,13 +4,14 @@
 # do not fit the TCC slots together; every --pmc pass carries --kernel-trace and nothing else: no sys / runtime / hip / hsa / memory-copy / marker trace next to counters).  Outputs under gpurun_out/<tag>_*;
 # `python profiles/summarize.py <tag> gpurun_out/<tag>_stats --pmc ...` then turns them into profiles/<tag>_*.
 set -e -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
+shift || true   # anything after the tag goes to bench.py (e.g. --coder rans8 --workload zipf: the sibling coders, summarize.py --side)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp
 export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-end-to-end $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -- $BENCH --steps 5 --warmup 2 > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/${TAG}_stats.log"
 echo "stats done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc_fetch" -- $BENCH --steps 2 --warmup 1 > /dev/null 2> "$OUT/${TAG}_pmc_fetch.log"
