@@ -22,8 +22,9 @@
 #define RCX_RANS_HEADER 1032u /* 258 dwords: cppans.h:521, :598 */
 #define RCX_RANS_BLOCKS 8     /* blocks per wave */
 
-// LDS of one block while encoding: cum[257] (kept for the header) | table[256] = start | freq << 16 | 64 staged input bytes
-#define RCX_RANS_ENC_LDS_DW (264 + 256 + 16)
+// LDS of one block while encoding: cum[257] (kept for the header) | table[256] = start | freq << 16 | 64 staged input bytes |
+// 256 bytes of output on its way to memory + 16 spare bytes (the eight-state encoder); a multiple of 16 bytes
+#define RCX_RANS_ENC_LDS_DW (264 + 256 + 16 + 64 + 4)
 // (the decoders' LDS: see rcx_dec_rans8_k and rcx_dec_rans1_quad_k)
 
 // Lanes of one octet talk through LDS without a barrier: a wave's LDS operations execute in order.  This keeps the
@@ -154,7 +155,7 @@ template <bool WORD>
 __global__ __launch_bounds__(256) void rcx_enc_rans_k(const u8* __restrict__ src, u64 n, u32 block, u64 nblocks, u8* __restrict__ slots,
                                                       u64 slot, u32* __restrict__ sizes, u32* __restrict__ starts, u32* status)
 {
-    __shared__ u32 lds_all[4 * RCX_RANS_BLOCKS * RCX_RANS_ENC_LDS_DW];
+    __shared__ __attribute__((aligned(16))) u32 lds_all[4 * RCX_RANS_BLOCKS * RCX_RANS_ENC_LDS_DW];
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const u32 j = lane & 7u, oct = lane >> 3;
     const u64 blk = ((u64)blockIdx.x * 4 + wave) * RCX_RANS_BLOCKS + oct;
@@ -183,10 +184,15 @@ __global__ __launch_bounds__(256) void rcx_enc_rans_k(const u8* __restrict__ src
         const u32 i = 8 * (rounds - 1) + j;
         next_byte = i < len ? in[i] : 0u;
     }
+    u8* const ring = stage + 64; // WORD: the stream's newest 256 bytes, byte a of the slot at ring[a & 255]
+    u32 drained = (u32)slot;     // WORD: everything from here up is in memory
     if (WORD) {
-        // cppans.h:591-594: symbol i goes to state i & 7 = lane j, so every lane codes the byte it loaded itself.  The eight
+        // cppans.h:591-594: symbol i goes to state i & 7 = lane j, so every lane codes the byte of its own column.  The eight
         // puts of a round are independent but for the order of their words: written backwards in the order 7 .. 0, i.e.
-        // ascending by lane in memory -- an octet ballot gives every emitting lane its place.
+        // ascending by lane in memory -- an octet ballot gives every emitting lane its place.  The words go into the
+        // block's ring in LDS (to a spare halfword for a lane that emits nothing: no branch) and leave for memory as whole
+        // 16-byte pieces every eight rounds: 2-byte stores straight to memory were one store instruction a round and
+        // kept the wave waiting (profiles/r03_rans8_pmc.json: 45 % of its cycles in s_waitcnt).
 #define RCX_RANS8_PUT(ACTIVE, SYM)                                                                                   \
     {                                                                                                                \
         const u32 e_ = table[(SYM)];                                                                                 \
@@ -198,13 +204,28 @@ __global__ __launch_bounds__(256) void rcx_enc_rans_k(const u8* __restrict__ src
         const bool room_ = ptr >= floor_ + 2 * words_;                                                               \
         overflow = overflow || !room_;                                                                               \
         ptr -= room_ ? 2 * words_ : 0u;                                                                              \
-        if (emit_ && !overflow) *reinterpret_cast<unsigned short*>(slot_base + ptr + 2 * before_) = (unsigned short)(x & 0xFFFFu); \
+        u8* const where_ = (emit_ && !overflow) ? ring + ((ptr + 2 * before_) & 255u) : ring + 256 + 2 * j;         \
+        *reinterpret_cast<unsigned short*>(where_) = (unsigned short)(x & 0xFFFFu);                                  \
         x = emit_ ? x >> 16 : x;                                                                                     \
         u32 rem_;                                                                                                    \
         const u32 q_ = rcx_div_small_quotient(x, freq_ ? freq_ : 1u, rem_); /* cppans.h:363 */                       \
         x = (ACTIVE) ? (q_ << 12) + rem_ + start_ : x;                                                               \
     }
-        // the byte of round k for this lane; rounds below 0 (the queue runs four rounds ahead) read the block's first byte
+        // whole 16-byte pieces of the ring go to memory, the highest first: lane k takes the k-th (at most 8 are due: eight
+        // rounds make at most 128 bytes and less than 16 stay behind)
+#define RCX_RANS8_DRAIN()                                                                                            \
+    {                                                                                                                \
+        rcx_octet_sync();                                                                                            \
+        const u32 lowest_ = (ptr + 15u) & ~15u;                                                                      \
+        const u32 due_ = drained > lowest_ ? (drained - lowest_) >> 4 : 0u;                                          \
+        if (live && j < due_) {                                                                                      \
+            const u32 a_ = drained - 16u * (j + 1u);                                                                 \
+            *reinterpret_cast<U4*>(slot_base + a_) = *reinterpret_cast<const U4*>(ring + (a_ & 255u));               \
+        }                                                                                                            \
+        drained -= 16u * due_;                                                                                       \
+        rcx_octet_sync();                                                                                            \
+    }
+        // the byte of round k for this lane; rounds below 0 (the queue runs ahead) read the block's first byte
         auto fetch = [&](u32 k) -> u32 { return in[k < rounds ? 8 * k + j : 0u]; };
         u32 r = rounds;
         if (r != 0) { // the block's last round: it may be short
@@ -221,30 +242,62 @@ __global__ __launch_bounds__(256) void rcx_enc_rans_k(const u8* __restrict__ src
         }
         if (common == 0xFFFFFFFFu) common = 0;
         if (!live) r = common; // (an octet without a block steps along, reading the start of the buffer; it stores nothing)
-        // The input bytes come four rounds ahead of their use: a load issued one round ahead (~400 cycles) arrives late.
-        u32 q0 = fetch(r - 1), q1 = fetch(r - 2), q2 = fetch(r - 3), q3 = fetch(r - 4); // q_k = the byte of round r - 1 - k
+        // Rounds above a multiple of eight, one by one (their bytes loaded as they come) ...
+        const bool by_eights = __all((reinterpret_cast<uintptr_t>(in) & 7u) == 0);
         u32 t = 0;
-        for (; t + 4 <= common; t += 4) {
-            RCX_RANS8_PUT(live, q0);
-            q0 = fetch(r - 5);
-            RCX_RANS8_PUT(live, q1);
-            q1 = fetch(r - 6);
-            RCX_RANS8_PUT(live, q2);
-            q2 = fetch(r - 7);
-            RCX_RANS8_PUT(live, q3);
-            q3 = fetch(r - 8);
-            r -= 4;
+        {
+            const u32 odd = by_eights ? (r & 7u) : common;
+            u32 q0 = fetch(r - 1);
+            for (; t < odd && t < common; ++t) {
+                const u32 q1 = fetch(r - 2);
+                RCX_RANS8_PUT(live, q0);
+                q0 = q1;
+                --r;
+                RCX_RANS8_DRAIN();
+            }
         }
-        for (; t < common; ++t) {
-            RCX_RANS8_PUT(live, q0);
-            q0 = q1, q1 = q2, q2 = q3, q3 = fetch(r - 5);
-            --r;
+        // ... then eight rounds = 64 bytes of the block at a time: lane k loads round (base + k)'s eight bytes -- two groups
+        // ahead, 16 rounds: a byte loaded four rounds ahead arrived late --, the octet turns them over through LDS (row k =
+        // round base + k, lane j reads column j), one round ahead of its use
+        if (t < common) {
+            auto load8 = [&](u32 base) -> u64 { // base = first round of the group, a multiple of 8 (or below 0: the block's first bytes)
+                return *reinterpret_cast<const u64*>(in + 8 * ((base < rounds ? base : 0u) + j));
+            };
+            u64 g0 = load8(r - 8), g1 = load8(r - 16);
+            while (t + 8 <= common) {
+                rcx_octet_sync();
+                *reinterpret_cast<u64*>(stage + 8 * j) = g0; // rounds r-8 .. r-1
+                g0 = g1;
+                g1 = load8(r - 24);
+                rcx_octet_sync();
+                u32 q = stage[8 * 7 + j];
+#pragma unroll
+                for (u32 i = 8; i-- > 0;) {
+                    const u32 cur_ = q;
+                    if (i != 0) q = stage[8 * (i - 1) + j];
+                    RCX_RANS8_PUT(live, cur_);
+                }
+                r -= 8;
+                t += 8;
+                RCX_RANS8_DRAIN();
+            }
         }
-        while (r != 0) { // blocks longer than the wave's shortest
-            RCX_RANS8_PUT(live, q0);
-            q0 = q1, q1 = q2, q2 = q3, q3 = fetch(r - 5);
-            --r;
+        // what is left: blocks longer than the wave's shortest, and streams that are not 8-byte aligned
+        {
+            u32 q0 = fetch(r - 1);
+            while (r != 0) {
+                const u32 q1 = fetch(r - 2);
+                RCX_RANS8_PUT(live, q0);
+                q0 = q1;
+                --r;
+                RCX_RANS8_DRAIN();
+            }
         }
+        // the bytes that never made a whole piece
+        rcx_octet_sync();
+        if (live && !overflow)
+            for (u32 a = ptr + j; a < drained; a += 8) slot_base[a] = ring[a & 255u];
+#undef RCX_RANS8_DRAIN
 #undef RCX_RANS8_PUT
     } else {
         // cppans.h:516-519: one state; every lane of the octet carries it, lane 0 stores; the octet stages symbols
@@ -969,6 +1022,9 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_rans1_quad_k(const u8* __r
     }
 
     if (full) {
+        // (Four pieces kept back and stored together as 64 bytes, as rcx_dec_quad_k does, bring the HBM writes down from 4.4 GB
+        // per GiB decoded to the bytes themselves but cost this kernel 4 % in time -- 11.3 -> 11.8 ms: it is bound by its
+        // vector instructions, not by memory -- so the pieces go one by one.)
         for (u32 i0 = 0; i0 < maxlen; i0 += 16) {
             in.topup();
             u32 w[4] = {0, 0, 0, 0};
