@@ -751,27 +751,29 @@ __global__ __launch_bounds__(64 * RCX_RANS1_ENC_WAVES) void rcx_enc_rans1_k(cons
 // half of them only move bytes.  So the work is cut where rANS allows it -- the state never needs anything back from the
 // bytes it has put out (no carry, unlike the range coder):
 //   wave 0, the coder:  table lookup (one symbol ahead), the renormalisation test, x = C(s, x); per symbol it hands over
-//                       one word: the 0..2 bytes that leave, in the order they go to memory, and how many;
-//   wave 1, the writer: gathers the bytes into dwords (a 64-bit register, the four oldest leave), puts the dwords into
-//                       a 64-byte ring per block in LDS and, once per chunk of 16 symbols, stores what has become whole
-//                       16-byte pieces, backwards from the end of the slot (no store, and no branch, per symbol).
+//                       one word: the state's low 16 bits before the step (the bytes that may leave) and how many leave;
+//   wave 1, the writer: writes BOTH bytes into a 64-byte ring per block in LDS, at the place of the next byte and the one
+//                       after, and moves on by the count -- a byte that did not leave is overwritten by the next one
+//                       that does: two byte writes and an add per symbol, no register to shift and mask, no select --
+//                       and, once per chunk of 16 symbols, stores what has become whole 16-byte pieces, backwards from
+//                       the end of the slot (no store, and no branch, per symbol).
 // They meet once per chunk (LDS records, double-buffered; s_waitcnt lgkmcnt(0) + s_barrier).  LDS: 128 KiB of tables
 // (2 KiB a block, as before) + 8 KiB of records + 4 KiB of rings: one workgroup of 64 blocks per CU, 256 for a GiB.
-// Measured (1 GiB of Zipf bytes, 64 KiB blocks): 8.49 -> 5.71 ms; each wave issues about 27 instructions a symbol at
-// about 7 cycles each (the two land on different SIMDs: an idle wave between them changes nothing).
+// Measured (1 GiB of Zipf bytes, 64 KiB blocks): 8.49 -> 5.71 ms with a writer that gathered dwords in a register (each
+// wave about 27 instructions a symbol at about 7 cycles each; the two land on different SIMDs: an idle wave between them
+// changes nothing), then with the byte ring and the coder relieved of arranging the bytes: see DESIGN.md section 3.6.
 // ---------------------------------------------------------------------------------------------------------
 #define RCX_R1W_CHUNK 16u
-#define RCX_R1W_RING_WORDS 16u /* a chunk makes at most 8 words and at most 3 stay behind after a drain */
+#define RCX_R1W_RING_WORDS 16u /* 64 bytes: a chunk makes at most 32, fewer than 16 stay behind after a drain, 2 are written ahead */
 #define RCX_R1W_TABLE_BYTES (256u * 64u * 8u)
 #define RCX_R1W_REC_DW (2u * RCX_R1W_CHUNK * 64u)
 #define RCX_R1W_LDS_BYTES (RCX_R1W_TABLE_BYTES + 4u * RCX_R1W_REC_DW + 4u * (RCX_R1W_RING_WORDS + 1u) * 64u + 4u * 64u)
 
 template <bool FULL>
 __device__ __forceinline__ void rcx_rans1w_pipeline(u32 wave, u32 lane, bool live, u32 len, u32 nchunks, const u8* in, const RcxRansSym* table,
-                                                    u32* rec, u32* oring, u8* slot_base, u32 slot, u32& x, u64& acc, u32& nacc, u32& words, u32& drained,
-                                                    bool& overflow)
+                                                    u32* rec, u32* oring, u8* slot_base, u32 slot, u32& x, u32& count, u32& drained, bool& overflow)
 {
-    const u32 max_words = (slot - (RCX_RANS_HEADER + 8u)) >> 2; // (the tail -- held bytes, state, header -- has its room below)
+    const u32 max_bytes = slot - (RCX_RANS_HEADER + 8u); // (the tail -- state, header -- has its room below)
     // the coder's look-ahead: the 16 bytes of the chunk it is about to code, and the first symbol's constants
     U4 cur, nxt;
     cur.x = cur.y = cur.z = cur.w = 0;
@@ -808,10 +810,8 @@ __device__ __forceinline__ void rcx_rans1w_pipeline(u32 wave, u32 lane, bool liv
                     const u32 cmpl = e.packed & 0x3FFFu, shift = (e.packed >> 14) & 15u, start = e.packed >> 18;
                     const u32 x_max = (16384u - cmpl) << 17;
                     const u32 n_out = (x_max <= x ? 1u : 0u) + (x_max <= (x >> 8) ? 1u : 0u); // bytes leaving: x & 0xFF, then (x >> 8) & 0xFF
-                    const u32 two = ((x & 0xFFu) << 8) | ((x >> 8) & 0xFFu);                    // (the later one ends up lower in memory)
-                    const u32 bytes = n_out == 2 ? two : (n_out == 1 ? (x & 0xFFu) : 0u);
                     const bool on = FULL || (live && i0 + s < len);
-                    out[t * 64u] = on ? (bytes | (n_out << 16)) : 0u;
+                    out[t * 64u] = on ? ((x & 0xFFFFu) | (n_out << 16)) : 0u;
                     const u32 xs = x >> (8 * n_out);
                     const u32 q = __umulhi(xs, e.rcp) >> shift;
                     const u32 bias = start + (cmpl == 16383u ? 16383u : 0u); // freq = 1: cppans.h:232-234
@@ -822,39 +822,30 @@ __device__ __forceinline__ void rcx_rans1w_pipeline(u32 wave, u32 lane, bool liv
             }
         } else if (k >= 1) { // ---- the writer: the records of the step before ----
             const u32* rs = rec + ((k - 1) & 1u) * (RCX_R1W_CHUNK * 64u) + lane;
-            u32* ring = oring + lane;
-            u32* dummy = oring + RCX_R1W_RING_WORDS * 64u + lane;
+            u8* const ring = reinterpret_cast<u8*>(oring + lane); // byte e of the stream (counted from the slot's end) at ring_at(e)
+            auto ring_at = [&](u32 e) -> u8* { return ring + (((e << 6) & 0xF00u) | (e & 3u)); }; // dword (e >> 2) & 15 of this lane, byte e & 3
             u32 r_next = rs[0];
 #pragma unroll
             for (u32 t = 0; t < RCX_R1W_CHUNK; ++t) {
                 const u32 r = r_next;
                 if (t + 1 < RCX_R1W_CHUNK) r_next = rs[(t + 1) * 64u];
-                const u32 sh = (r >> 13) & 24u; // 8 x the count
-                acc = (acc << sh) | (u64)(r & 0xFFFFu);
-                nacc += r >> 16;
-                // with 4 or 5 bytes held the four oldest leave as one dword
-                const bool due = nacc >= 4;
-                const u32 keep8 = (8 * nacc) & 8u; // 8 x (nacc - 4) when due: 0 or 8
-                const u32 word = (u32)(acc >> keep8);
-                const bool room = words < max_words;
-                overflow = overflow || (due && !room);
-                const bool put = due && room;
-                u32* where = put ? ring + (words % RCX_R1W_RING_WORDS) * 64u : dummy;
-                *where = word;
-                words += put ? 1u : 0u;
-                acc = due ? (acc & ((1ull << keep8) - 1ull)) : acc;
-                nacc -= due ? 4u : 0u;
+                *ring_at(count) = (u8)r;            // x & 0xFF: leaves first, so it lies highest
+                *ring_at(count + 1) = (u8)(r >> 8); // (x >> 8) & 0xFF
+                count += r >> 16;                   // 0, 1 or 2 of them count
             }
-            // whole 16-byte pieces go to memory: words d .. d+3 lie at slot - 4 (d + 4), the newest lowest
-            while (__any(live && drained + 4 <= words)) {
-                if (live && drained + 4 <= words) {
+            overflow = overflow || count > max_bytes; // (cannot happen with the slot rcx_block_bound_for gives: 2 bytes a symbol at most)
+            // whole 16-byte pieces go to memory: bytes 16 p .. 16 p + 15 lie at slot - 16 (p + 1) .., the highest-numbered lowest
+            while (__any(live && !overflow && 16u * (drained + 1u) <= count)) {
+                if (live && !overflow && 16u * (drained + 1u) <= count) {
+                    const u32* w = oring + lane;
+                    const u32 d = 4u * drained;
                     U4 piece;
-                    piece.x = ring[((drained + 3) % RCX_R1W_RING_WORDS) * 64u];
-                    piece.y = ring[((drained + 2) % RCX_R1W_RING_WORDS) * 64u];
-                    piece.z = ring[((drained + 1) % RCX_R1W_RING_WORDS) * 64u];
-                    piece.w = ring[((drained + 0) % RCX_R1W_RING_WORDS) * 64u];
-                    *reinterpret_cast<U4*>(slot_base + slot - 4u * (drained + 4u)) = piece;
-                    drained += 4;
+                    piece.x = rcx_bswap(w[((d + 3) % RCX_R1W_RING_WORDS) * 64u]);
+                    piece.y = rcx_bswap(w[((d + 2) % RCX_R1W_RING_WORDS) * 64u]);
+                    piece.z = rcx_bswap(w[((d + 1) % RCX_R1W_RING_WORDS) * 64u]);
+                    piece.w = rcx_bswap(w[((d + 0) % RCX_R1W_RING_WORDS) * 64u]);
+                    *reinterpret_cast<U4*>(slot_base + slot - 16u * (drained + 1u)) = piece;
+                    drained += 1;
                 }
             }
         }
@@ -890,22 +881,18 @@ __global__ __launch_bounds__(128) void rcx_enc_rans1w_k(const u8* __restrict__ s
 
     u8* const slot_base = slots + (live ? blk : 0) * slot;
     u32 x = 1u << 23; // cppans.h:260-263
-    u64 acc = 0;      // bytes not yet in a dword, the newest lowest
-    u32 nacc = 0, words = 0, drained = 0;
+    u32 count = 0, drained = 0; // the writer's: bytes put out, 16-byte pieces stored
     bool overflow = false;
-    if (full) rcx_rans1w_pipeline<true>(wave, lane, live, len, nchunks, in, table, rec, oring, slot_base, (u32)slot, x, acc, nacc, words, drained, overflow);
-    else rcx_rans1w_pipeline<false>(wave, lane, live, len, nchunks, in, table, rec, oring, slot_base, (u32)slot, x, acc, nacc, words, drained, overflow);
+    if (full) rcx_rans1w_pipeline<true>(wave, lane, live, len, nchunks, in, table, rec, oring, slot_base, (u32)slot, x, count, drained, overflow);
+    else rcx_rans1w_pipeline<false>(wave, lane, live, len, nchunks, in, table, rec, oring, slot_base, (u32)slot, x, count, drained, overflow);
     if (wave == 0) final_x[lane] = x;
     rcx_lds_barrier();
     if (wave == 1 && live) {
-        // what the ring still holds, the bytes still held, the state (cppans.h:289-299), the header (:521-527)
-        const u32* ring = oring + lane;
-        for (u32 d = drained; d < words; ++d) *reinterpret_cast<u32*>(slot_base + slot - 4u * (d + 1u)) = ring[(d % RCX_R1W_RING_WORDS) * 64u];
-        u32 ptr = (u32)slot - 4u * words;
-        for (u32 k = nacc; k-- > 0;) { // oldest first: it sits highest
-            ptr -= 1;
-            slot_base[ptr] = (u8)(acc >> (8 * k));
-        }
+        // what the ring still holds, the state (cppans.h:289-299), the header (:521-527)
+        const u8* ring = reinterpret_cast<const u8*>(oring + lane);
+        if (overflow) count = 0;
+        for (u32 e = 16u * drained; e < count; ++e) slot_base[(u32)slot - 1u - e] = ring[((e << 6) & 0xF00u) | (e & 3u)];
+        u32 ptr = (u32)slot - count;
         const u32 xf = final_x[lane];
         ptr -= 4;
         slot_base[ptr] = (u8)xf, slot_base[ptr + 1] = (u8)(xf >> 8), slot_base[ptr + 2] = (u8)(xf >> 16), slot_base[ptr + 3] = (u8)(xf >> 24);
