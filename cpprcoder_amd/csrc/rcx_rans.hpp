@@ -494,38 +494,55 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_rans8_k(const u8* __restri
         }
         fast_groups = (mine == 0xFFFFFFF8u || !even) ? 0u : mine;
     }
-    for (u32 g = 0; g < fast_groups; ++g) {
-        if (rcx_any(live && (pending || p + 128 >= filled))) { // some octet has a piece to put into its ring, or to ask for
-            if (pending) {
-                *reinterpret_cast<U4*>(ring + ((filled + 16 * j) & (RCX_R8_RING_BYTES - 1))) = pend;
-                filled += 128;
+    // (in the fast loop the eight symbols a lane decodes in eight steps -- one column of the octet's 8 x 8 bytes -- stay in
+    // two registers and the octet turns the 8 x 8 over in registers: lane t ends up with the eight symbols of step t, its
+    // 8 bytes of the output.  Through LDS that was a byte write per step and a read per eight, and the LDS unit is what
+    // bounds this kernel: profiles/r03_rans8_pmc.json, 5.7 LDS instructions a step, 55 % of its cycles bank conflicts)
+    const u32 sel_half = (j & 2u) ? 0x03020706u : 0x05040100u; // v_perm selectors: own 16 bits kept, the partner's (lane ^ 2) taken
+    const u32 sel_byte = (j & 1u) ? 0x03070105u : 0x06020400u; // own bytes kept, the partner's (lane ^ 1) taken
+    for (u32 g8 = 0; g8 < fast_groups; g8 += 8) {
+        u32 col_lo = 0, col_hi = 0;
+#pragma unroll
+        for (u32 st = 0; st < 8; ++st) {
+            if (rcx_any(live && (pending || p + 128 >= filled))) { // some octet has a piece to put into its ring, or to ask for
+                if (pending) {
+                    *reinterpret_cast<U4*>(ring + ((filled + 16 * j) & (RCX_R8_RING_BYTES - 1))) = pend;
+                    filled += 128;
+                }
+                pending = live && p + 128 >= filled;
+                if (pending) pend = load16(filled);
             }
-            pending = live && p + 128 >= filled;
-            if (pending) pend = load16(filled);
+            // cppans.h:636-639 (simdDecSym :412-440)
+            const u32 slot_ = x & 4095u;
+            const u32 f = first[slot_ >> 2];
+            const u32 e0 = table[f], e1 = table[f + 1], e2 = table[f + 2], e3 = table[f + 3];
+            u32 e = e0;
+            if ((e1 & 4095u) <= slot_) e = e1;
+            if ((e2 & 4095u) <= slot_) e = e2;
+            if ((e3 & 4095u) <= slot_) e = e3;
+            if (st < 4) col_lo |= (e >> 24) << (8 * st);
+            else col_hi |= (e >> 24) << (8 * (st - 4));
+            x = (((e >> 12) & 4095u) + 1u) * (x >> 12) + slot_ - (e & 4095u); // freq * (x >> 12) + bias
+            // cppans.h:640-641 (simdDecRenorm :443-488): the states below 2^16 take one word each, in state order
+            const bool need = x < (1u << 16);
+            const u32 mask = rcx_octet_ballot(need, lane);
+            const u32 o = (p + 2 * (u32)__popc(mask & ((1u << j) - 1u))) & (RCX_R8_RING_BYTES - 1);
+            const u32 word = *reinterpret_cast<const unsigned short*>(ring + o);
+            x = need ? ((x << 16) | word) : x;
+            p += 2 * (u32)__popc(mask);
         }
-        // cppans.h:636-639 (simdDecSym :412-440)
-        const u32 slot_ = x & 4095u;
-        const u32 f = first[slot_ >> 2];
-        const u32 e0 = table[f], e1 = table[f + 1], e2 = table[f + 2], e3 = table[f + 3];
-        u32 e = e0;
-        if ((e1 & 4095u) <= slot_) e = e1;
-        if ((e2 & 4095u) <= slot_) e = e2;
-        if ((e3 & 4095u) <= slot_) e = e3;
-        obuf[8 * (g & 7u) + j] = (u8)(e >> 24);
-        x = (((e >> 12) & 4095u) + 1u) * (x >> 12) + slot_ - (e & 4095u); // freq * (x >> 12) + bias
-        // cppans.h:640-641 (simdDecRenorm :443-488): the states below 2^16 take one word each, in state order
-        const bool need = x < (1u << 16);
-        const u32 mask = rcx_octet_ballot(need, lane);
-        const u32 o = (p + 2 * (u32)__popc(mask & ((1u << j) - 1u))) & (RCX_R8_RING_BYTES - 1);
-        const u32 word = *reinterpret_cast<const unsigned short*>(ring + o);
-        x = need ? ((x << 16) | word) : x;
-        p += 2 * (u32)__popc(mask);
-        if ((g & 7u) == 7u) { // eight steps = 64 symbols of the block: 8 bytes per lane
-            rcx_octet_sync();
-            const u64 eight = *reinterpret_cast<const u64*>(obuf + 8 * j);
-            if (live) *reinterpret_cast<u64*>(out + 8 * (g - 7) + 8 * j) = eight;
-            rcx_octet_sync();
+        // the 8 x 8 turned over: 4-byte blocks between lanes j and j ^ 4, 2-byte blocks between j and j ^ 2, bytes between j and j ^ 1
+        {
+            const u32 send = (j & 4u) ? col_lo : col_hi;
+            const u32 got = rcx_dpp<0x1B>(rcx_dpp<0x141>(send)); // row_half_mirror then quad_perm [3,2,1,0]: lane j ^ 4
+            col_lo = (j & 4u) ? got : col_lo;
+            col_hi = (j & 4u) ? col_hi : got;
+            col_lo = rcx_perm(rcx_dpp<0x4E>(col_lo), col_lo, sel_half); // quad_perm [2,3,0,1]: lane j ^ 2
+            col_hi = rcx_perm(rcx_dpp<0x4E>(col_hi), col_hi, sel_half);
+            col_lo = rcx_perm(rcx_dpp<0xB1>(col_lo), col_lo, sel_byte); // quad_perm [1,0,3,2]: lane j ^ 1
+            col_hi = rcx_perm(rcx_dpp<0xB1>(col_hi), col_hi, sel_byte);
         }
+        if (live) *reinterpret_cast<u64*>(out + 8 * g8 + 8 * j) = (u64)col_lo | ((u64)col_hi << 32); // step g8 + j's eight symbols
     }
     for (u32 g = fast_groups; g < max_groups; ++g) {
         const bool on = g < groups;
