@@ -69,6 +69,25 @@ def baseline_config(name: str, n: int, block: int, world: int) -> str:
     return "none of BASELINE.json's configs (a variation for diagnosis)"
 
 
+def usable_cpus() -> int:
+    """The host cores this process may really use: the visible ones, capped by the container's CPU quota (cgroup v2
+    cpu.max, v1 cfs quota) -- the GPU box shows 256 hardware threads and grants 16 cores' worth of time."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(data: np.ndarray, block: int, coder: int = 0, blksort: bool = False):
     """The reference's CPU coder on a bounded sample of the same bytes the GPU coded, all host cores.  With blksort the
     reference's block sort runs in front of it and behind it (BlkSort::encode / decode, as test/main.cpp:961-986)."""
@@ -77,7 +96,7 @@ def cpu_baseline(data: np.ndarray, block: int, coder: int = 0, blksort: bool = F
     chk = oracle_lib.reference() or oracle_lib.oracle()
     if blksort and chk.bwt is None:
         chk = oracle_lib.oracle()
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     t0 = time.time()
     coded = chk.bwt_encode(data, threads=cores) if blksort else data
     slots, sizes = chk.encode_blocks(coded, block, coder=coder, threads=cores)
@@ -472,7 +491,7 @@ def main() -> None:
                 gpu_sizes = (offs[1: k + 1] - offs[:k]).cpu().numpy()
                 line["cpu_baseline"]["block_sizes_equal_gpu"] = bool(np.array_equal(gpu_sizes, cpu_sizes[:k].astype(np.int64)))
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
-                line["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+                line["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": usable_cpus(), "kind": "port", "sample": f"failed: {e}"}
         if world == 1 and not args.no_end_to_end and not args.blksort:
             try:
                 line["end_to_end"] = end_to_end(ctx, host_src, block, coder)
