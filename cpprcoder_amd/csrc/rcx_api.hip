@@ -712,6 +712,8 @@ int rcx_encode_blocks(rcx_ctx* c, int coder, const uint8_t* src, uint64_t n, uin
         return RCX_OK;
     };
     job.work_streams = 2; // (measured: a third encode chunk in flight gains nothing and delays the copies back)
+    job.caller_in = src;
+    job.caller_out = dst;
     r = host_run(c, p, job);
     const int latched = rcx_ctx_sync_status(c, nullptr, nullptr);
     if (r != RCX_OK) return r;
@@ -787,6 +789,8 @@ int rcx_decode_blocks(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
         return RCX_OK;
     };
     job.decode = true;
+    job.caller_in = comp;
+    job.caller_out = dst;
     r = host_run(c, p, job);
     const int latched = rcx_ctx_sync_status(c, nullptr, nullptr);
     if (r != RCX_OK) return r;
@@ -1192,6 +1196,175 @@ int rcx_dstream_decode(rcx_dstream* d, const uint8_t* bytes, uint64_t size, uint
     return RCX_PENDING;
 }
 
+// ---------------------------------------------------------------------------
+// The resumable single-stream encoder: AdaptiveRangeEncoder<T>::encode fed piece by piece (cpprcoder.h:697-720).
+// ---------------------------------------------------------------------------
+struct rcx_estream {
+    rcx_ctx* ctx = nullptr;
+    RcxEState* state = nullptr;   // device
+    RcxEState* backup = nullptr;  // device: the state before the last call (rcx_estream_rewind)
+    u8* slot = nullptr;           // device: the stream so far
+    u64 slot_bytes = 0;
+    u8* tail_backup = nullptr;    // device: the bytes of `slot` the last call could change
+    u64 tail_cap = 0, tail_from = 0, tail_bytes = 0;
+    u8* in = nullptr;             // device: the piece being fed
+    u64 in_cap = 0;
+    u32* result = nullptr;        // device
+    u32* result_host = nullptr;   // pinned
+    u32 declared = 0, consumed = 0;
+    u64 written = 0;              // payload bytes handed on so far (the reference's writeByte count)
+    u32 backup_consumed = 0;
+    u64 backup_written = 0;
+    bool have_backup = false, dead = false, finished = false;
+    u64 pos_hint = 0;             // payload bytes in memory after the last call (how far a call can have changed things)
+};
+
+int rcx_estream_create(rcx_ctx* c, uint32_t declared, rcx_estream** out)
+{
+    if (!c || !out || declared > RCX_MAX_STREAM) return RCX_E_ARG;
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(c->device));
+    rcx_estream* e = new (std::nothrow) rcx_estream();
+    if (!e) return RCX_E_NOMEM;
+    e->ctx = c;
+    e->declared = declared;
+    const u32 block = declared < RCX_MIN_BLOCK ? RCX_MIN_BLOCK : declared;
+    e->slot_bytes = declared <= RCX_MAX_BLOCK ? rcx_block_bound(block) : (((u64)declared + declared / 8 + 4096 + 15) & ~(u64)15);
+    RcxEState zero;
+    memset(&zero, 0, sizeof(zero));
+    zero.declared = declared;
+    if (hipMalloc(reinterpret_cast<void**>(&e->state), sizeof(RcxEState)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&e->backup), sizeof(RcxEState)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&e->slot), e->slot_bytes + 64) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&e->result), 8 * sizeof(u32)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&e->result_host), 8 * sizeof(u32), hipHostMallocDefault) != hipSuccess ||
+        hipMemcpy(e->state, &zero, sizeof(zero), hipMemcpyHostToDevice) != hipSuccess) {
+        rcx_estream_destroy(e);
+        return RCX_E_NOMEM;
+    }
+    *out = e;
+    return RCX_OK;
+}
+
+void rcx_estream_destroy(rcx_estream* e)
+{
+    if (!e) return;
+    if (e->ctx) (void)hipSetDevice(e->ctx->device);
+    if (e->state) (void)hipFree(e->state);
+    if (e->backup) (void)hipFree(e->backup);
+    if (e->slot) (void)hipFree(e->slot);
+    if (e->tail_backup) (void)hipFree(e->tail_backup);
+    if (e->in) (void)hipFree(e->in);
+    if (e->result) (void)hipFree(e->result);
+    if (e->result_host) (void)hipHostFree(e->result_host);
+    delete e;
+}
+
+int rcx_estream_encode(rcx_estream* e, const uint8_t* bytes, uint64_t size, uint8_t* dst, uint64_t dst_cap, uint64_t sink_room,
+                       uint64_t* emitted_now, uint32_t* tail_bytes, uint32_t* request_size)
+{
+    if (!e || !emitted_now || (size && !bytes) || (dst_cap && !dst)) return RCX_E_ARG;
+    *emitted_now = 0;
+    if (tail_bytes) *tail_bytes = 0;
+    if (request_size) *request_size = 0;
+    if (e->finished) return RCX_OK;
+    if (e->dead) { // the reference's coder is of no use after a full sink either (cpprcoder.h:708-711)
+        if (request_size) *request_size = e->declared - e->consumed;
+        return RCX_PENDING;
+    }
+    if (size > (u64)(e->declared - e->consumed)) return RCX_E_ARG; // CPPRCODER_ASSERT, cpprcoder.h:700
+    HIP_TRY(hipSetDevice(e->ctx->device));
+    // what this call may change, kept for rcx_estream_rewind: the state, and the stream from the first byte the reference
+    // has not written yet (a carry stops there) to a little past what is in memory
+    {
+        const u64 from = 4 + e->written, upto = 4 + e->pos_hint + 16 < e->slot_bytes ? 4 + e->pos_hint + 16 : e->slot_bytes;
+        const u64 span = upto > from ? upto - from : 0;
+        if (span > e->tail_cap) {
+            if (e->tail_backup) (void)hipFree(e->tail_backup);
+            e->tail_backup = nullptr;
+            e->tail_cap = 0;
+            u64 cap = 4096;
+            while (cap < span) cap *= 2;
+            if (hipMalloc(reinterpret_cast<void**>(&e->tail_backup), cap) != hipSuccess) return RCX_E_NOMEM;
+            e->tail_cap = cap;
+        }
+        HIP_TRY(hipMemcpy(e->backup, e->state, sizeof(RcxEState), hipMemcpyDeviceToDevice));
+        if (span) HIP_TRY(hipMemcpy(e->tail_backup, e->slot + from, span, hipMemcpyDeviceToDevice));
+        e->tail_from = from;
+        e->tail_bytes = span;
+        e->backup_consumed = e->consumed;
+        e->backup_written = e->written;
+        e->have_backup = true;
+    }
+    if (size > e->in_cap) {
+        if (e->in) (void)hipFree(e->in);
+        e->in = nullptr;
+        e->in_cap = 0;
+        u64 cap = 1u << 16;
+        while (cap < size) cap *= 2;
+        if (hipMalloc(reinterpret_cast<void**>(&e->in), cap) != hipSuccess) return RCX_E_NOMEM;
+        e->in_cap = cap;
+    }
+    if (size) HIP_TRY(hipMemcpy(e->in, bytes, size, hipMemcpyHostToDevice));
+    const u32 room = sink_room > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)sink_room;
+    hipLaunchKernelGGL(rcx_enc_resume_k, dim3(1), dim3(64), 0, nullptr, e->state, e->in, (u32)size, e->slot, (u32)(e->slot_bytes > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : e->slot_bytes), room,
+                       e->result);
+    if (hipGetLastError() != hipSuccess) return RCX_E_HIP;
+    HIP_TRY(hipMemcpy(e->result_host, e->result, 8 * sizeof(u32), hipMemcpyDeviceToHost));
+    const u32 written = e->result_host[0], fail_at = e->result_host[1], finished = e->result_host[2], stream_size = e->result_host[3],
+              flush_fails = e->result_host[4], overflow = e->result_host[5];
+    if (overflow) return RCX_E_CAPACITY; // (the slot is the bound of a stream of this size: cannot happen)
+    u64 now = (u64)written - e->written; // payload bytes the reference passed to writeByte during this call
+    int status = RCX_PENDING;
+    u32 tail = 0;
+    if (fail_at != 0xFFFFFFFFu) { // its sink filled inside symbol fail_at (cpprcoder.h:708-711)
+        // it writes byte by byte until writeByte fails, so the sink is exactly full: also the part of the last group (held
+        // byte + pending run) that still fitted, which the kernel's count of whole groups does not include
+        now = sink_room;
+        e->consumed = fail_at;
+        e->dead = true;
+    } else if (finished) { // cpprcoder.h:744-762: the held byte and the pending run through writeByte, low through write(4)
+        const u64 through_write_byte = (u64)stream_size - 8 - e->written;
+        if (flush_fails) {
+            now = through_write_byte < sink_room ? through_write_byte : sink_room; // finish() gave up; encode() says Success (cpprcoder.h:716)
+        } else {
+            now = through_write_byte;
+            tail = 4;
+        }
+        e->consumed = e->declared;
+        e->finished = true;
+        status = RCX_OK;
+    } else {
+        e->consumed += (u32)size;
+    }
+    *emitted_now = now + tail;
+    if (now + tail > dst_cap) return RCX_E_CAPACITY;
+    if (now) HIP_TRY(hipMemcpy(dst, e->slot + 4 + e->written, now, hipMemcpyDeviceToHost));
+    if (tail) HIP_TRY(hipMemcpy(dst + now, e->slot + stream_size - 4, 4, hipMemcpyDeviceToHost));
+    e->written += now;
+    e->pos_hint = e->result_host[6]; // how far the stream reaches in memory: what the next call can change ends a little past it
+    if (tail_bytes) *tail_bytes = tail;
+    if (status == RCX_PENDING && request_size) *request_size = e->declared - e->consumed;
+    return status;
+}
+
+// Back to before the last rcx_estream_encode call.  For a sink that only tells by failing how much room it has: encode with
+// no limit, hand the bytes on, and if the sink fails after k of them rewind and encode the same piece with sink_room = k to
+// learn which symbol the reference was coding then.
+int rcx_estream_rewind(rcx_estream* e)
+{
+    if (!e || !e->have_backup) return RCX_E_ARG;
+    HIP_TRY(hipSetDevice(e->ctx->device));
+    HIP_TRY(hipMemcpy(e->state, e->backup, sizeof(RcxEState), hipMemcpyDeviceToDevice));
+    if (e->tail_bytes) HIP_TRY(hipMemcpy(e->slot + e->tail_from, e->tail_backup, e->tail_bytes, hipMemcpyDeviceToDevice));
+    e->consumed = e->backup_consumed;
+    e->written = e->backup_written;
+    e->dead = false;
+    e->finished = false;
+    e->have_backup = false;
+    return RCX_OK;
+}
+
 #if defined(RCX_STAMP_DEC)
 int rcx_debug_dec_stamps(unsigned long long* out8)
 {
@@ -1396,6 +1569,8 @@ int bwt_host(rcx_ctx* c, bool forward, const uint8_t* src, uint64_t n, uint8_t* 
         *span = HostSpan{c->h_out + k * cb * unit_out, dst + k * cb * unit_out, out_bytes(k)};
         return RCX_OK;
     };
+    job.caller_in = src;
+    job.caller_out = dst;
     r = host_run(c, p, job);
     const int latched = rcx_ctx_sync_status(c, nullptr, nullptr);
     if (r != RCX_OK) return r;

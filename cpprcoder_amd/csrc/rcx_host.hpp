@@ -170,6 +170,8 @@ struct HostJob {
     std::function<int(u64, hipStream_t)> launch;     // the chunk's kernels (+ small copies into HostPipe::words)
     std::function<int(u64, HostSpan*)> out;          // device -> caller's bytes; may return an error
     bool decode = false;                             // the output is a decoder's (HostPipe::out_mode_decode)
+    const void* caller_in = nullptr;                 // the caller's buffers (to see whether they are pinned already)
+    const void* caller_out = nullptr;
 };
 
 struct HostRun {
@@ -187,6 +189,7 @@ struct HostRun {
     std::vector<HostSpan> outs;
     u64 outs_ready = 0;
     std::vector<std::pair<void*, u64>> registered; // register mode: the caller's ranges pinned for this call
+    int in_mode = RCX_HOST_DIRECT, out_mode = RCX_HOST_DIRECT; // this call's ways across the link (host_run decides)
     // RCX_HOST_TRACE=1: when each stage of each chunk happened, to stderr at the end of the call (diagnostic)
     bool trace = false;
     std::chrono::steady_clock::time_point t0;
@@ -235,7 +238,7 @@ void host_feeder(HostRun* r, int t)
 {
     HostPipe* p = r->p;
     if (hipSetDevice(r->c->device) != hipSuccess) return r->fail(RCX_E_HIP);
-    const bool staged = p->in_mode == RCX_HOST_STAGED;
+    const bool staged = r->in_mode == RCX_HOST_STAGED;
     hipStream_t s = p->in_streams[t];
     u8* slot[2] = {staged ? p->pin + ((u64)t * 2 + 0) * p->piece : nullptr, staged ? p->pin + ((u64)t * 2 + 1) * p->piece : nullptr};
     u64 turn = 0;
@@ -264,7 +267,7 @@ void host_feeder(HostRun* r, int t)
             ok = landed();
             if (!ok) break;
             if (len) {
-                if (p->in_mode == RCX_HOST_REGISTER) host_register(r, span.from + at, len);
+                if (r->in_mode == RCX_HOST_REGISTER) host_register(r, span.from + at, len);
                 ok = hipMemcpyAsync(span.to + at, staged ? slot[turn & 1] : span.from + at, len, hipMemcpyHostToDevice, s) == hipSuccess;
                 ++turn;
             }
@@ -282,7 +285,7 @@ void host_drainer(HostRun* r, int t)
 {
     HostPipe* p = r->p;
     if (hipSetDevice(r->c->device) != hipSuccess) return r->fail(RCX_E_HIP);
-    const int out_mode = r->job->decode ? p->out_mode_decode : p->out_mode;
+    const int out_mode = r->out_mode;
     const bool staged = out_mode == RCX_HOST_STAGED;
     hipStream_t s = p->out_stream;
     u8* const mine = staged ? p->pin + ((p->in_mode == RCX_HOST_STAGED ? 2ull * p->feeders : 0) + 2ull * t) * p->piece : nullptr;
@@ -362,6 +365,21 @@ int host_run(rcx_ctx* c, HostPipe* p, const HostJob& job)
     r.trace = getenv("RCX_HOST_TRACE") != nullptr;
     r.t0 = std::chrono::steady_clock::now();
     const u64 K = job.chunks;
+    // Memory the caller has pinned itself (hipHostMalloc, hipHostRegister) needs neither staging nor pinning: the copies are
+    // plain DMA and the calls return at once.
+    auto pinned = [](const void* ptr) {
+        if (!ptr) return false;
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, ptr) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return a.type == hipMemoryTypeHost;
+    };
+    r.in_mode = p->in_mode;
+    r.out_mode = job.decode ? p->out_mode_decode : p->out_mode;
+    if (pinned(job.caller_in)) r.in_mode = RCX_HOST_DIRECT;
+    if (pinned(job.caller_out)) r.out_mode = RCX_HOST_DIRECT;
     r.ins.resize(K);
     r.in_first_piece.resize(K + 1);
     r.fed.assign(K, 0);
@@ -369,6 +387,7 @@ int host_run(rcx_ctx* c, HostPipe* p, const HostJob& job)
     r.done.assign(K, nullptr);
     int rc = host_pipe_pin(p);
     if (rc != RCX_OK) return rc;
+    if (r.trace) fprintf(stderr, "rcx_host modes: in %d out %d (0 direct, 1 staged, 2 register)\n", r.in_mode, r.out_mode);
     u64 pieces = 0;
     for (u64 k = 0; k < K; ++k) {
         r.ins[k] = job.in(k);

@@ -391,6 +391,89 @@ __global__ __launch_bounds__(64) void rcx_dec_resume_k(RcxDState* __restrict__ s
     result[5] = (u32)(consumed >> 32);
 }
 
+// ===========================================================================
+// The resumable single-stream encoder (rcx_estream_*, include/rcx.h): AdaptiveRangeEncoder<T>::encode called piece by
+// piece (cpprcoder.h:697-720).  One lane; low, range, the model, the bytes it still holds and where the reference's
+// delayed writer stands (held byte + pending 0xFF run, cpprcoder.h:764-802) live in `st` between launches.  After a
+// launch the stream's payload in `slot` is complete up to the bytes the coder still holds in its register -- those
+// are written behind it as they stand, without being given up -- so that the host can hand on exactly the bytes the
+// reference has passed to writeByte by then: payload[written before, written now).  A byte the reference has written
+// never changes (a carry stops at its held byte), so what the host copies is final.
+// ===========================================================================
+struct alignas(16) RcxEState {
+    U4 tree[RCX_GROUPS];
+    u64 acc;
+    u32 low, range, total, started;
+    u32 declared, consumed;      // symbols taken so far
+    u32 nacc8, pos, overflow;
+    u32 trk_written, trk_pending, trk_fail_at;
+};
+
+// result: {payload bytes the reference has written so far, symbol at which its sink filled or 0xFFFFFFFF, 1 if this
+// launch finished the stream, stream size if finished, 1 if only finish() ran into the full sink, slot overflow,
+// payload bytes in memory}
+__global__ __launch_bounds__(64) void rcx_enc_resume_k(RcxEState* __restrict__ st, const u8* __restrict__ in, u32 count, u8* __restrict__ slot,
+                                                       u32 slot_bytes, u32 sink_room, u32* __restrict__ result)
+{
+    __shared__ U4 lds[RCX_GROUPS * RCX_LANES];
+    if (threadIdx.x != 0) return;
+    Tree tree{reinterpret_cast<u32*>(lds)};
+    EncLane enc;
+    u32 total, consumed;
+    const u32 declared = st->declared;
+    if (!st->started) { // cpprcoder.h:678-695
+        enc.begin(slot, 0, slot_bytes, declared);
+        tree.reset();
+        total = 256;
+        consumed = 0;
+    } else {
+        enc.base = slot;
+        enc.off = 4;
+        enc.cap = (slot_bytes - 4) & ~3u;
+        enc.leader = true;
+        enc.low = st->low, enc.range = st->range, enc.acc = st->acc, enc.nacc8 = st->nacc8, enc.pos = st->pos, enc.overflow = st->overflow;
+        enc.trk_written = st->trk_written, enc.trk_pending = st->trk_pending, enc.trk_fail_at = st->trk_fail_at;
+        total = st->total;
+        consumed = st->consumed;
+        for (u32 g = 0; g < RCX_GROUPS; ++g) tree.store(g, st->tree[g]);
+    }
+    // the sink takes `sink_room` more bytes through writeByte from here on
+    enc.trk_cap = sink_room > 0xFFFFFFFFu - enc.trk_written ? 0xFFFFFFFFu : enc.trk_written + sink_room;
+    u32 i = 0;
+    for (; i < count && enc.trk_fail_at == 0xFFFFFFFFu; ++i) enc.template step_long<true>(tree, in[i], total, consumed + i);
+    u32 finished = 0, size = 0, flush_fails = 0;
+    const bool failed = enc.trk_fail_at != 0xFFFFFFFFu;
+    if (!failed) consumed += count;
+    else consumed = enc.trk_fail_at; // the reference stops inside that symbol (cpprcoder.h:708-711): its state is of no use any more, nor is this one
+    if (!failed && consumed >= declared) { // cpprcoder.h:714-717
+        flush_fails = enc.track_flush_fails() ? 1u : 0u;
+        size = enc.finish();
+        finished = 1;
+    } else {
+        // what the register holds, behind what is in memory, as it stands (a carry that has run off it first)
+        const u32 extra = (u32)(enc.acc >> enc.nacc8);
+        if (extra) {
+            enc.carry_into_memory(extra);
+            enc.acc &= (1ull << enc.nacc8) - 1ull;
+        }
+        const u32 n = enc.nacc8 >> 3;
+        u8* out = enc.payload();
+        for (u32 k = 0; k < n; ++k)
+            if (enc.pos + k < enc.cap) out[enc.pos + k] = (u8)(enc.acc >> (8 * (n - 1 - k)));
+    }
+    st->low = enc.low, st->range = enc.range, st->acc = enc.acc, st->nacc8 = enc.nacc8, st->pos = enc.pos, st->overflow = enc.overflow;
+    st->trk_written = enc.trk_written, st->trk_pending = enc.trk_pending, st->trk_fail_at = enc.trk_fail_at;
+    st->total = total, st->consumed = consumed, st->started = 1;
+    for (u32 g = 0; g < RCX_GROUPS; ++g) st->tree[g] = tree.group(g);
+    result[0] = enc.trk_written;
+    result[1] = enc.trk_fail_at;
+    result[2] = finished;
+    result[3] = size;
+    result[4] = flush_fails;
+    result[5] = enc.overflow;
+    result[6] = finished ? size - 4 : enc.pos + (enc.nacc8 >> 3); // payload bytes in memory now (the register's included)
+}
+
 #include "rcx_oct.hpp"
 #if defined(RCX_WITH_VARIANTS) // superseded kernels, kept for comparison: only in the diagnostic build (build.py build_variants)
 #include "variants/rcx_variants.hpp"

@@ -29,6 +29,7 @@ EXPORTS = (
     "rcx_ctx_get_timing", "rcx_ctx_last_redo",
     "rcx_block_bound_for", "rcx_encode_bound_for", "rcx_ctx_reserve_for",
     "rcx_dstream_create", "rcx_dstream_destroy", "rcx_dstream_decode",
+    "rcx_estream_create", "rcx_estream_destroy", "rcx_estream_encode", "rcx_estream_rewind",
     "rcx_comm_unique_id", "rcx_comm_create", "rcx_comm_destroy", "rcx_comm_rank", "rcx_comm_size", "rcx_exchange_plan",
     "rcx_allgatherv_segments",
     "rcx_bwt_encode_bound", "rcx_bwt_decode_bound", "rcx_bwt_decoded_size", "rcx_bwt_reserve", "rcx_bwt_encode_device",
@@ -93,6 +94,11 @@ def lib() -> C.CDLL:
         L.rcx_dstream_destroy.restype, L.rcx_dstream_destroy.argtypes = None, [vp]
         L.rcx_dstream_decode.restype = i32
         L.rcx_dstream_decode.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64), C.POINTER(u32)]
+        L.rcx_estream_create.restype, L.rcx_estream_create.argtypes = i32, [vp, u32, C.POINTER(vp)]
+        L.rcx_estream_destroy.restype, L.rcx_estream_destroy.argtypes = None, [vp]
+        L.rcx_estream_encode.restype = i32
+        L.rcx_estream_encode.argtypes = [vp, vp, u64, vp, u64, u64, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32)]
+        L.rcx_estream_rewind.restype, L.rcx_estream_rewind.argtypes = i32, [vp]
         L.rcx_comm_unique_id.restype, L.rcx_comm_unique_id.argtypes = i32, [vp]
         L.rcx_comm_create.restype, L.rcx_comm_create.argtypes = i32, [i32, vp, i32, i32, C.POINTER(vp)]
         L.rcx_comm_destroy.restype, L.rcx_comm_destroy.argtypes = None, [vp]
@@ -313,9 +319,12 @@ class Context:
         st = lib().rcx_stream_decode(self._h, coder, src.ctypes.data, len(src), dst.ctypes.data, sink_capacity, C.byref(size), C.byref(req))
         return st, req.value, bytes(dst[: size.value])
 
-    # ---- the resumable decoder ----------------------------------------------
+    # ---- the resumable decoder / encoder --------------------------------------
     def dstream(self) -> "DStream":
         return DStream(self)
+
+    def estream(self, declared: int) -> "EStream":
+        return EStream(self, declared)
 
     # ---- per-kernel device time -------------------------------------------
     def set_timing(self, enabled: bool) -> None:
@@ -360,3 +369,42 @@ class DStream:
         got, req = C.c_uint64(), C.c_uint32()
         st = lib().rcx_dstream_decode(self._h, src.ctypes.data if len(src) else None, len(src), dst.ctypes.data, room, C.byref(got), C.byref(req))
         return st, req.value, bytes(dst[: got.value])
+
+
+class EStream:
+    """One rcx_estream: AdaptiveRangeEncoder<T>::encode fed piece by piece (cpprcoder.h:697-720)."""
+
+    def __init__(self, ctx: Context, declared: int):
+        self._h = C.c_void_p()
+        _check(lib().rcx_estream_create(ctx._h, declared, C.byref(self._h)), "rcx_estream_create")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().rcx_estream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def encode(self, piece, sink_room: int | None = None):
+        """-> (status, request_size, bytes for writeByte, bytes for write)"""
+        src = _np_u8(piece)
+        cap = 3 * len(src) + 64 + (1 << 16)
+        while True:
+            dst = np.full(cap + 16, 0xA5, dtype=np.uint8)
+            got, tail, req = C.c_uint64(), C.c_uint32(), C.c_uint32()
+            st = lib().rcx_estream_encode(self._h, src.ctypes.data if len(src) else None, len(src), dst.ctypes.data, cap,
+                                          (1 << 64) - 1 if sink_room is None else sink_room, C.byref(got), C.byref(tail), C.byref(req))
+            assert bool((dst[cap:] == 0xA5).all()), "rcx_estream_encode wrote past dst_cap"
+            if st == E_CAPACITY:  # a pending run longer than the guess: once more with the size it asked for
+                _check(lib().rcx_estream_rewind(self._h), "rcx_estream_rewind")
+                cap = int(got.value) + 64
+                continue
+            body = int(got.value) - int(tail.value)
+            return st, req.value, bytes(dst[:body]), bytes(dst[body: body + tail.value])
+
+    def rewind(self) -> None:
+        _check(lib().rcx_estream_rewind(self._h), "rcx_estream_rewind")

@@ -187,12 +187,16 @@ private:
     u8* buffer_;
 };
 
-//--- AdaptiveRangeEncoder (cpprcoder.h:626-802)
+//--- AdaptiveRangeEncoder (cpprcoder.h:626-802): the encoder's state lives on the GPU between calls (rcx_estream), and
+//    every call passes to the sink what the reference passes to it during that call -- the payload bytes that have become
+//    final (everything but the coder's held byte and the 0xFF bytes pending behind it, cpprcoder.h:764-802) through
+//    writeByte(), the last call also the final low through write(4) (cpprcoder.h:744-762).
 template<class T = MemoryStream>
 class AdaptiveRangeEncoder
 {
 public:
-    AdaptiveRangeEncoder() : stream_(nullptr), umcompressedSize_(0), inSize_(0), dead_(false) {}
+    AdaptiveRangeEncoder() : stream_(nullptr), encoder_(nullptr), umcompressedSize_(0), inSize_(0), dead_(false) {}
+    ~AdaptiveRangeEncoder() { rcx_estream_destroy(encoder_); }
 
     // cpprcoder.h:678-695: the header goes out at once through write()
     bool initialize(T& stream, u32 umcompressedSize)
@@ -201,8 +205,8 @@ public:
         umcompressedSize_ = umcompressedSize;
         inSize_ = 0;
         dead_ = false;
-        input_.clear();
-        input_.reserve(umcompressedSize);
+        rcx_estream_destroy(encoder_);
+        encoder_ = nullptr;
         u8 bytes[4] = {static_cast<u8>(umcompressedSize), static_cast<u8>(umcompressedSize >> 8),
                        static_cast<u8>(umcompressedSize >> 16), static_cast<u8>(umcompressedSize >> 24)};
         return 0 < stream_->write(4, bytes);
@@ -213,10 +217,50 @@ public:
     {
         CPPRCODER_ASSERT((inSize_ + size) <= umcompressedSize_);
         if (dead_) return {Status_Pending, umcompressedSize_ - inSize_};
-        input_.insert(input_.end(), bytes, bytes + size);
+        rcx_ctx* ctx = facade_context();
+        if (!ctx) return {Status_Error, 0};
+        // The whole stream in one call (how the reference's harness drives it, test/main.cpp:330): the many-lane kernels
+        // run one chain three to four times as fast as the resumable one-lane coder below.
+        if (inSize_ == 0 && !encoder_ && static_cast<u32>(size) == umcompressedSize_) return whole(ctx, bytes);
+        if (!encoder_ && rcx_estream_create(ctx, umcompressedSize_, &encoder_) != RCX_OK) return {Status_Error, 0};
+        const uint64_t piece = static_cast<uint64_t>(size);
+        if (out_.size() < 3 * piece + 4096) out_.resize(3 * piece + 4096);
+        uint64_t got = 0;
+        uint32_t tail = 0, req = 0;
+        int st = rcx_estream_encode(encoder_, bytes, piece, out_.data(), out_.size(), UINT64_MAX, &got, &tail, &req);
+        if (st == RCX_E_CAPACITY) { // a pending run longer than the guess: once more with the room it asked for
+            out_.resize(got + 64);
+            if (rcx_estream_rewind(encoder_) != RCX_OK) return {Status_Error, 0};
+            st = rcx_estream_encode(encoder_, bytes, piece, out_.data(), out_.size(), UINT64_MAX, &got, &tail, &req);
+        }
+        if (st != RCX_OK && st != RCX_PENDING) return {Status_Error, 0};
+        // Replay the reference's sink calls: payload byte by byte through writeByte (never grows) ...
+        const uint64_t through_write_byte = got - tail;
+        for (uint64_t i = 0; i < through_write_byte; ++i) {
+            if (!stream_->writeByte(out_[i])) {
+                // The sink took i bytes of this call.  What the reference returns then depends on where it was: inside a symbol
+                // (Pending, the symbols before it counted, cpprcoder.h:708-711) or in finish() (Success, cpprcoder.h:716).  The
+                // device knows: the same piece again, against a sink with room for exactly i bytes.
+                dead_ = true; // the reference's coder is unusable from here on too
+                if (rcx_estream_rewind(encoder_) != RCX_OK) return {Status_Error, 0};
+                uint64_t got2 = 0;
+                const int again = rcx_estream_encode(encoder_, bytes, piece, out_.data(), out_.size(), i, &got2, &tail, &req);
+                if (again == RCX_PENDING) {
+                    inSize_ = umcompressedSize_ - req;
+                    return {Status_Pending, req};
+                }
+                if (again == RCX_OK) {
+                    inSize_ = umcompressedSize_;
+                    return {Status_Success, 0};
+                }
+                return {Status_Error, 0};
+            }
+        }
+        // ... and the last four bytes through write (may grow): cpprcoder.h:756-761, result ignored as in the reference
+        if (tail) stream_->write(static_cast<s32>(tail), out_.data() + through_write_byte);
         inSize_ += static_cast<u32>(size);
-        if (umcompressedSize_ <= inSize_) return flush();
-        return {Status_Pending, umcompressedSize_ - inSize_};
+        if (st == RCX_OK) return {Status_Success, 0};
+        return {Status_Pending, req};
     }
 
     // cpprcoder.h:722-742
@@ -226,15 +270,13 @@ private:
     AdaptiveRangeEncoder(const AdaptiveRangeEncoder&) = delete;
     AdaptiveRangeEncoder& operator=(const AdaptiveRangeEncoder&) = delete;
 
-    Result flush()
+    Result whole(rcx_ctx* ctx, const u8* bytes)
     {
-        rcx_ctx* ctx = facade_context();
-        if (!ctx) return {Status_Error, 0};
         const u32 n = umcompressedSize_;
         std::vector<u8> out(static_cast<size_t>(rcx_block_bound(n < RCX_MIN_BLOCK ? RCX_MIN_BLOCK : n)) + 64);
         uint64_t size = 0;
         uint32_t req = 0;
-        if (rcx_stream_encode(ctx, RCX_CODER_ADAPTIVE, input_.data(), n, out.data(), out.size(), out.size(), &size, &req) != RCX_OK)
+        if (rcx_stream_encode(ctx, RCX_CODER_ADAPTIVE, bytes, n, out.data(), out.size(), out.size(), &size, &req) != RCX_OK)
             return {Status_Error, 0};
         // Replay the reference's sink calls: payload byte by byte through writeByte (never grows),
         // the last four bytes through write (may grow) -- cpprcoder.h:744-762, 783-800.
@@ -245,23 +287,26 @@ private:
                 // Which symbol was being coded when byte i did not fit?  Ask the device to replay the
                 // reference's delayed writer against a sink that accepts exactly i bytes.
                 uint64_t size2 = 0;
-                int st = rcx_stream_encode(ctx, RCX_CODER_ADAPTIVE, input_.data(), n, out.data(), out.size(), i, &size2, &req);
+                int st = rcx_stream_encode(ctx, RCX_CODER_ADAPTIVE, bytes, n, out.data(), out.size(), i, &size2, &req);
                 if (st == RCX_PENDING) {
                     inSize_ = n - req;
                     return {Status_Pending, req}; // cpprcoder.h:708-711
                 }
+                inSize_ = n;
                 return {Status_Success, 0}; // only finish() ran into the full sink (cpprcoder.h:716)
             }
         }
         stream_->write(4, out.data() + payload_end); // result ignored, as in the reference
+        inSize_ = n;
         return {Status_Success, 0};
     }
 
     T* stream_;
+    rcx_estream* encoder_;
     u32 umcompressedSize_;
     u32 inSize_;
     bool dead_;
-    std::vector<u8> input_;
+    std::vector<u8> out_;
 };
 
 //--- AdaptiveRangeDecoder (cpprcoder.h:809-940): the decoder's state lives on the GPU between calls (rcx_dstream)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define RCX_VERSION 210 /* 0.2.1 */
+#define RCX_VERSION 300 /* 0.3.0 */
 
 /* Status codes.  0 / 1 / -1 are the reference's Status enum (cpprcoder.h:112-117). */
 enum {
@@ -182,6 +182,35 @@ int rcx_dstream_create(rcx_ctx* ctx, rcx_dstream** out);
 void rcx_dstream_destroy(rcx_dstream* stream);
 int rcx_dstream_decode(rcx_dstream* stream, const uint8_t* bytes, uint64_t size, uint8_t* dst, uint64_t dst_cap,
                        uint64_t* produced_now, uint32_t* request_size);
+
+/*
+ * The adaptive encoder as a resumable object: AdaptiveRangeEncoder<T>::initialize + encode(size, bytes) called piece by
+ * piece (cpprcoder.h:678-720).  The reference writes to its sink as it goes: after every encode() call the sink holds the
+ * header, and every payload byte except the one the coder still holds and the 0xFF bytes pending behind it
+ * (cpprcoder.h:764-802); the last call adds those through writeByte() and the final low through write(4)
+ * (cpprcoder.h:744-762).  This object gives a caller exactly those bytes call by call; its state stays on the GPU.
+ *   rcx_estream_create   `declared` = the size passed to initialize() (the caller writes the 4 header bytes itself,
+ *       cpprcoder.h:689-694)
+ *   rcx_estream_encode   feed `size` more bytes (not more than are still expected: RCX_E_ARG, the reference asserts).
+ *       dst receives what the reference passes to its sink during this call, *emitted_now bytes: payload bytes for
+ *       writeByte() and, on the last call, *tail_bytes = 4 bytes behind them that go through write().  sink_room = how
+ *       many bytes the caller's sink still takes through writeByte (UINT64_MAX: no limit).  Returns RCX_PENDING with
+ *       *request_size = declared - fed so far while input is expected; RCX_OK when the stream is complete -- also when
+ *       only finish() ran into the full sink (cpprcoder.h:716): dst then holds what fitted and *tail_bytes is 0.  If the
+ *       sink fills while a symbol is coded: RCX_PENDING with *request_size as cpprcoder.h:708-711 sets it (declared -
+ *       symbols coded before that one), dst holding the bytes that fitted; the object is then of no further use, as the
+ *       reference's.  dst_cap >= 3 * size + 8 + the pending run is always enough; RCX_E_CAPACITY says how much is needed
+ *       in *emitted_now (the call can be repeated after rcx_estream_rewind).
+ *   rcx_estream_rewind   back to before the last rcx_estream_encode call: for a sink that only tells by failing how
+ *       much room it had -- encode without a limit, hand the bytes on, and if the sink fails after k of them rewind and
+ *       encode the same piece with sink_room = k to learn what the reference would have returned.
+ */
+typedef struct rcx_estream rcx_estream;
+int rcx_estream_create(rcx_ctx* ctx, uint32_t declared, rcx_estream** out);
+void rcx_estream_destroy(rcx_estream* stream);
+int rcx_estream_encode(rcx_estream* stream, const uint8_t* bytes, uint64_t size, uint8_t* dst, uint64_t dst_cap, uint64_t sink_room,
+                       uint64_t* emitted_now, uint32_t* tail_bytes, uint32_t* request_size);
+int rcx_estream_rewind(rcx_estream* stream);
 
 /*
  * The block sort (blksort.h): the Burrows-Wheeler transform of 32 KiB blocks the reference harness runs in front of

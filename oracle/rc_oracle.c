@@ -674,6 +674,39 @@ rco_result rco_adaptive_encode_chunked(const uint8_t* src, uint32_t n, uint32_t 
     return r;
 }
 
+/* The same, and how many bytes the sink held after initialize() (sizes[0]) and after every encode() call
+ * (sizes[1..]): what a caller that looks at its sink between calls sees (cpprcoder.h:764-802: everything the coder has
+ * made except its held byte and the 0xFF bytes pending behind it).  -> the number of entries written. */
+uint32_t rco_adaptive_encode_trace(const uint8_t* src, uint32_t n, uint32_t piece, uint8_t* dst, uint64_t dst_cap, uint64_t* out_size,
+                                   uint32_t* sizes, uint32_t max_sizes, rco_result* last)
+{
+    rco_stream s;
+    rco_encoder e;
+    rco_result r = {RCO_ERROR, 0};
+    uint32_t calls = 0;
+    rco_stream_init_cap(&s, (int32_t)dst_cap);
+    if (rco_encoder_begin(&e, &s, n)) {
+        r.status = RCO_SUCCESS;
+        if (calls < max_sizes) sizes[calls++] = (uint32_t)s.size;
+        if (n == 0) {
+            r = rco_encoder_put(&e, 0, src);
+            if (calls < max_sizes) sizes[calls++] = (uint32_t)s.size;
+        }
+        for (uint32_t at = 0; at < n;) {
+            uint32_t len = (n - at < piece) ? (n - at) : piece;
+            r = rco_encoder_put(&e, (int32_t)len, src + at);
+            at += len;
+            if (calls < max_sizes) sizes[calls++] = (uint32_t)s.size;
+            if (r.status == RCO_ERROR || (r.status == RCO_PENDING && at < n && r.request_size != n - at)) break; /* the sink filled */
+        }
+    }
+    if (last) *last = r;
+    if (out_size) *out_size = (uint64_t)s.size;
+    if (dst) memcpy(dst, s.buffer, (size_t)((uint64_t)s.size < dst_cap ? (uint64_t)s.size : dst_cap));
+    rco_stream_free(&s);
+    return calls;
+}
+
 rco_result rco_adaptive_decode_chunked(const uint8_t* comp, uint64_t comp_size, uint32_t piece, uint8_t* dst, uint64_t dst_cap, uint64_t* out_size)
 {
     rco_stream s;

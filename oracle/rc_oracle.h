@@ -124,6 +124,8 @@ uint64_t rco_fnv1a64(const uint8_t* p, uint64_t n);
 /* tests can run one script against both.                              */
 /* ------------------------------------------------------------------ */
 rco_result rco_adaptive_encode_chunked(const uint8_t* src, uint32_t n, uint32_t piece, uint8_t* dst, uint64_t dst_cap, uint64_t* out_size);
+uint32_t rco_adaptive_encode_trace(const uint8_t* src, uint32_t n, uint32_t piece, uint8_t* dst, uint64_t dst_cap, uint64_t* out_size,
+                                   uint32_t* sizes, uint32_t max_sizes, rco_result* last);
 rco_result rco_adaptive_decode_chunked(const uint8_t* comp, uint64_t comp_size, uint32_t piece, uint8_t* dst, uint64_t dst_cap, uint64_t* out_size);
 void rco_model_probe(const uint8_t* syms, uint64_t n, uint32_t* total, uint32_t* freq256, uint32_t* cum256,
                      const uint32_t* targets, uint32_t ntargets, uint32_t* found_count, uint8_t* found_code);

@@ -85,6 +85,36 @@ ref_result ref_adaptive_encode_chunked(const uint8_t* src, uint32_t n, uint32_t 
     return r;
 }
 
+// The same, and the sink's size after initialize() and after every encode() call (see rco_adaptive_encode_trace).
+uint32_t ref_adaptive_encode_trace(const uint8_t* src, uint32_t n, uint32_t piece, uint8_t* dst, uint64_t dst_cap, uint64_t* out_size,
+                                   uint32_t* sizes, uint32_t max_sizes, ref_result* last)
+{
+    MemoryStream s(static_cast<s32>(dst_cap));
+    AdaptiveRangeEncoder<> enc;
+    ref_result r = {Status_Error, 0};
+    uint32_t calls = 0;
+    if (enc.initialize(s, n)) {
+        Result q = {Status_Success, 0};
+        if (calls < max_sizes) sizes[calls++] = static_cast<uint32_t>(s.size());
+        if (n == 0) {
+            q = enc.encode(0, src);
+            if (calls < max_sizes) sizes[calls++] = static_cast<uint32_t>(s.size());
+        }
+        for (uint32_t at = 0; at < n;) {
+            uint32_t len = (n - at < piece) ? (n - at) : piece;
+            q = enc.encode(static_cast<s32>(len), src + at);
+            at += len;
+            if (calls < max_sizes) sizes[calls++] = static_cast<uint32_t>(s.size());
+            if (q.status_ == Status_Error || (q.status_ == Status_Pending && at < n && q.requestSize_ != n - at)) break; // the sink filled
+        }
+        r.status = q.status_;
+        r.request_size = q.requestSize_;
+    }
+    if (last) *last = r;
+    copy_out(s, dst, dst_cap, out_size);
+    return calls;
+}
+
 ref_result ref_adaptive_decode(const uint8_t* comp, uint64_t comp_size, uint8_t* dst, uint64_t dst_cap, uint64_t* out_size)
 {
     MemoryStream s(static_cast<s32>(dst_cap));

@@ -4,6 +4,8 @@
 // are compared with the oracle there.
 //
 //   facade_test enc  <in> <out> <sink_capacity> <piece>   piece: 0 = one call, N = pieces of N bytes, -1 = encode(u8)
+//   facade_test enct <in> <out> <sink_capacity> <piece>   as enc in pieces of N bytes; prints the sink's size after initialize()
+//                                                         and after every encode() call (what a caller sees between calls)
 //   facade_test dec  <in> <out> <sink_capacity> <piece>
 //   facade_test senc|sdec <in> <out> <sink_capacity>       static RangeEncoder<>::encode / decode
 //   facade_test blocks <in> <out> <block>                  BlockCoder round trip; out = compacted streams
@@ -56,6 +58,31 @@ int main(int argc, char** argv)
         }
         dump(argv[3], sink.get(), static_cast<size_t>(sink.size()));
         printf("%d %u %d %d\n", static_cast<int>(r.status_), r.requestSize_, sink.size(), sink.capacity());
+        return 0;
+    }
+    if (!strcmp(argv[1], "enct")) {
+        s32 cap = atoi(argv[4]);
+        int piece = atoi(argv[5]);
+        MemoryStream sink(cap);
+        AdaptiveRangeEncoder<> enc;
+        if (!enc.initialize(sink, static_cast<u32>(in.size()))) return 3;
+        Result r = {Status_Success, 0};
+        std::vector<s32> sizes(1, sink.size());
+        if (in.empty()) {
+            r = enc.encode(0, in.data());
+            sizes.push_back(sink.size());
+        }
+        for (size_t at = 0; at < in.size();) {
+            size_t len = in.size() - at < static_cast<size_t>(piece) ? in.size() - at : piece;
+            r = enc.encode(static_cast<s32>(len), in.data() + at);
+            at += len;
+            sizes.push_back(sink.size());
+            if (r.status_ == Status_Error || (r.status_ == Status_Pending && at < in.size() && r.requestSize_ != in.size() - at)) break; // the sink filled
+        }
+        dump(argv[3], sink.get(), static_cast<size_t>(sink.size()));
+        printf("%d %u %d %d\n", static_cast<int>(r.status_), r.requestSize_, sink.size(), sink.capacity());
+        for (size_t i = 0; i < sizes.size(); ++i) printf("%d ", sizes[i]);
+        printf("\n");
         return 0;
     }
     if (!strcmp(argv[1], "dec")) {

@@ -59,6 +59,10 @@ class Checker:
         self._adec.restype, self._adec.argtypes = _Result, [u8p, C.c_uint64, u8p, C.c_uint64, u64p]
         self._aencc = getattr(L, p + "adaptive_encode_chunked")
         self._aencc.restype, self._aencc.argtypes = _Result, [u8p, C.c_uint32, C.c_uint32, u8p, C.c_uint64, u64p]
+        self._aenct = getattr(L, p + "adaptive_encode_trace", None)
+        if self._aenct is not None:
+            self._aenct.restype = C.c_uint32
+            self._aenct.argtypes = [u8p, C.c_uint32, C.c_uint32, u8p, C.c_uint64, u64p, C.c_void_p, C.c_uint32, C.POINTER(_Result)]
         self._adecc = getattr(L, p + "adaptive_decode_chunked")
         self._adecc.restype, self._adecc.argtypes = _Result, [u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint64, u64p]
         self._senc = getattr(L, p + "static_encode")
@@ -152,6 +156,18 @@ class Checker:
     def adaptive_encode_chunked(self, data, piece, sink_capacity=None):
         res, out, size = self._oneshot(self._aencc, data, sink_capacity, piece)
         return (res.status, res.request_size), out, size
+
+    def adaptive_encode_trace(self, data, piece, sink_capacity=None):
+        """encode() in pieces of `piece` bytes -> ((status, request_size) of the last call, the sink's bytes, the sink's size
+        after initialize() and after every encode() call)."""
+        src = _u8(data)
+        cap = self.default_capacity(len(src)) if sink_capacity is None else int(sink_capacity)
+        out = np.zeros(max(cap, 16) + 32, dtype=np.uint8)
+        calls = (len(src) + piece - 1) // piece + 3
+        sizes = np.zeros(calls, dtype=np.uint32)
+        size, last = C.c_uint64(), _Result()
+        got = self._aenct(src.ctypes.data, len(src), piece, out.ctypes.data, cap, C.byref(size), sizes.ctypes.data, calls, C.byref(last))
+        return (last.status, last.request_size), bytes(out[: min(size.value, cap)]), [int(x) for x in sizes[:got]]
 
     def adaptive_decode(self, comp, sink_capacity):
         res, out, size = self._oneshot(self._adec, comp, sink_capacity)

@@ -226,3 +226,27 @@ def test_long_streams_and_big_blocks(oracle, golden):
         slots, sizes = oracle.encode_blocks(data, t["block"], coder=0 if t["coder"] == "adaptive" else 1, threads=4)
         assert [int(x) for x in sizes] == t["sizes"]
         assert ["%016x" % oracle_lib.fnv1a64(slots[b, : int(sizes[b])]) for b in range(len(sizes))] == t["fnv1a64"]
+
+
+def test_encode_traces_from_the_reference_build(oracle, reference):
+    """AdaptiveRangeEncoder<T>::encode in pieces: the sink's size after initialize() and after every call, the last call's
+    result and the sink's bytes -- tests/golden/encode_traces.json, made by the real reference (make_golden_traces.py)."""
+    import hashlib
+    import json
+    import os
+
+    import trace_cases
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "golden", "encode_traces.json")) as f:
+        want = {c["name"]: c for c in json.load(f)["cases"]}
+    seen = 0
+    for name, data, piece, cap in trace_cases.cases():
+        w = want[name]
+        assert hashlib.sha256(bytes(data)).hexdigest() == w["input_sha256"], name
+        for chk in (oracle, reference):
+            if chk is None:
+                continue
+            (st, rq), sink, sizes = chk.adaptive_encode_trace(data, piece, cap)
+            assert [st, rq] == w["status"] and sizes == w["sink_sizes"] and hashlib.sha256(sink).hexdigest() == w["sink_sha256"], (name, chk.kind)
+        seen += 1
+    assert seen >= 15

@@ -30,13 +30,23 @@ def one(args):
     nblocks = rcx.block_count(n, block)
     for wl in args.workloads.split(","):
         data = workloads.by_name(wl, n, 12345)
+        if args.pinned:  # the caller's buffers pinned by the caller (here: torch's pinned allocator = hipHostMalloc)
+            import torch
+            pin = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+            pin.numpy()[:] = data
+            data = pin.numpy()
         warm_dst = np.zeros(rcx.encode_bound(1 << 26, block, coder), dtype=np.uint8)
         ctx.encode_blocks_into(data[: 1 << 26], block, warm_dst, np.zeros(rcx.block_count(1 << 26, block) + 1, dtype=np.uint64), coder)  # allocations, streams
         rows = {}
         for state in ("fresh", "reused", "reused", "reused"):
             if state == "fresh" or "dst" not in rows:
-                dst = np.empty(rcx.encode_bound(n, block, coder), dtype=np.uint8)
-                out = np.empty(n, dtype=np.uint8)
+                if args.pinned:
+                    import torch
+                    keep = (torch.empty(rcx.encode_bound(n, block, coder), dtype=torch.uint8, pin_memory=True), torch.empty(n, dtype=torch.uint8, pin_memory=True))
+                    dst, out = keep[0].numpy(), keep[1].numpy()
+                else:
+                    dst = np.empty(rcx.encode_bound(n, block, coder), dtype=np.uint8)
+                    out = np.empty(n, dtype=np.uint8)
                 offsets = np.zeros(nblocks + 1, dtype=np.uint64)
                 rows["dst"] = True
             t0 = time.perf_counter()
@@ -47,7 +57,7 @@ def one(args):
             assert got == n and np.array_equal(out, data)
             e, d = rows.get(state, (1e9, 1e9))
             rows[state] = (min(e, t1 - t0), min(d, t2 - t1))
-        print(json.dumps(dict(tag, workload=wl, coder=args.coder, bytes=n, block=block, ratio=round(size / n, 6),
+        print(json.dumps(dict(tag, pinned_by_caller=bool(args.pinned), workload=wl, coder=args.coder, bytes=n, block=block, ratio=round(size / n, 6),
                               host_encode_MBps=round(n / 1e6 / rows["reused"][0], 1), host_decode_MBps=round(n / 1e6 / rows["reused"][1], 1),
                               host_encode_MBps_fresh_destination=round(n / 1e6 / rows["fresh"][0], 1),
                               host_decode_MBps_fresh_destination=round(n / 1e6 / rows["fresh"][1], 1),
@@ -80,12 +90,13 @@ def main():
     ap.add_argument("--bytes", type=int, default=1 << 30)
     ap.add_argument("--block", type=int, default=65536)
     ap.add_argument("--blksort", action="store_true")
+    ap.add_argument("--pinned", action="store_true", help="the caller's buffers are pinned host memory (hipHostMalloc through torch)")
     ap.add_argument("--serial", action="store_true", help="also the unpipelined path (RCX_HOST_SERIAL=1), for comparison")
     args = ap.parse_args()
     if not args.modes and not args.serial:
         return one(args)
     base = [sys.executable, os.path.abspath(__file__), "--workloads", args.workloads, "--coder", args.coder, "--bytes", str(args.bytes),
-            "--block", str(args.block)] + (["--blksort"] if args.blksort else [])
+            "--block", str(args.block)] + (["--blksort"] if args.blksort else []) + (["--pinned"] if args.pinned else [])
     runs = []
     if args.serial:
         runs.append({"RCX_HOST_SERIAL": "1"})
