@@ -42,6 +42,7 @@
 #include <thread>
 
 
+
 namespace
 {
 
