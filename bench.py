@@ -135,7 +135,7 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def launch_ranks(n: int, argv: list[str]) -> int:
+def launch_ranks(n: int, argv: list[str], limit_s: float = 1500.0) -> int:
     """`python bench.py --gpus N` typed plainly: start N fresh rank processes (this one has not touched the GPU and never
     does), hand rank 0's stdout through, stderr of all ranks as it comes.  Returns the exit code: 0 only if every rank's is."""
     import subprocess
@@ -151,7 +151,13 @@ def launch_ranks(n: int, argv: list[str]) -> int:
     reader.start()
     code = 0
     alive = set(range(n))
+    started = time.time()
     while alive:
+        if time.time() - started > limit_s and code == 0:  # a rank that hangs must not hang the whole run
+            code = 124
+            print(f"bench.py: the ranks did not finish within {limit_s:.0f} s; stopping them", file=sys.stderr)
+            for o in alive:
+                procs[o].terminate()
         for r in sorted(alive):
             rc = procs[r].poll()
             if rc is None:
@@ -264,11 +270,12 @@ def main() -> None:
     ap.add_argument("--dry-launch", action="store_true",
                     help="rehearse the launcher without a GPU: every rank prints the environment it was started with and exits")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurement")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-started ranks get before they are stopped")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_launch):
         # typed plainly: this process only starts the ranks (it has imported nothing that initialises HIP)
-        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout))
     if args.dry_launch:
         keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
         mine = {k: os.environ.get(k) for k in keys}
