@@ -6,6 +6,7 @@
 // calls rcx_encode_blocks_device / rcx_decode_blocks_device per buffer.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -18,16 +19,30 @@
 namespace
 {
 
-#define HIP_TRY(expr)                         \
-    do {                                      \
-        hipError_t e_ = (expr);               \
-        if (e_ != hipSuccess) return RCX_E_HIP; \
+// RCX_DEBUG=1 (diagnostic): say which HIP call failed, on stderr; the status code stays the only thing a caller gets
+#define HIP_TRY(expr)                                                                                              \
+    do {                                                                                                           \
+        hipError_t e_ = (expr);                                                                                    \
+        if (e_ != hipSuccess) {                                                                                    \
+            if (getenv("RCX_DEBUG")) fprintf(stderr, "rcx: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return RCX_E_HIP;                                                                                      \
+        }                                                                                                          \
     } while (0)
 
 struct EventPair {
     hipEvent_t a, b;
     int what;
 };
+
+// Every entry point begins here.  Since HIP 7 an error code returned by ANY earlier runtime call of this thread -- the
+// caller's, another library's -- stays in the thread's "last error" until somebody reads it, and the launches below are
+// checked by reading it: what was there before is not ours to report (found by a test that ran after another one had left
+// an error behind: the first kernel launch of the next call "failed").
+inline hipError_t rcx_enter_device(int device)
+{
+    (void)hipGetLastError();
+    return hipSetDevice(device);
+}
 
 struct HostPipe; // rcx_host.hpp: streams, threads' staging and bookkeeping of the host-buffer entry points
 
@@ -293,7 +308,7 @@ int rcx_ctx_create(int device, rcx_ctx** out)
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return RCX_E_HIP; // no CPU fallback: fail loudly
     if (device < 0 || device >= count) return RCX_E_ARG;
-    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(rcx_enter_device(device));
     rcx_ctx* c = new (std::nothrow) rcx_ctx();
     if (!c) return RCX_E_NOMEM;
     c->device = device;
@@ -354,14 +369,14 @@ void rcx_ctx_destroy(rcx_ctx* c)
 int rcx_ctx_reserve(rcx_ctx* c, uint64_t n, uint32_t block)
 {
     if (!c || !block_ok(block)) return RCX_E_ARG;
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(rcx_enter_device(c->device));
     return reserve(c, n, block);
 }
 
 int rcx_ctx_reserve_for(rcx_ctx* c, int coder, uint64_t n, uint32_t block)
 {
     if (!c || !block_ok(block) || !coder_ok(coder)) return RCX_E_ARG;
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(rcx_enter_device(c->device));
     return reserve(c, n, block, coder);
 }
 
@@ -369,7 +384,7 @@ int rcx_ctx_sync_status(rcx_ctx* c, void* stream, uint64_t* first_bad_block)
 {
     if (!c) return RCX_E_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(rcx_enter_device(c->device));
     HIP_TRY(hipMemcpyAsync(c->status_host, c->status, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
     const u32 init[2] = {0u, 0xFFFFFFFFu};
     HIP_TRY(hipStreamSynchronize(s));
@@ -390,7 +405,7 @@ int rcx_encode_blocks_device(rcx_ctx* c, int coder, const void* d_src, uint64_t 
     if (!c || !block_ok(block) || !d_offsets || (n && (!d_src || !d_dst))) return RCX_E_ARG;
     if (!coder_ok(coder)) return RCX_E_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(rcx_enter_device(c->device));
     const u64 nblocks = rcx_block_count(n, block);
     if (nblocks == 0) return hipMemsetAsync(d_offsets, 0, sizeof(u64), s) == hipSuccess ? RCX_OK : RCX_E_HIP;
     if (nblocks > 0x7FFFFFFFull) return RCX_E_ARG; // grid.x limit with 8 blocks per workgroup to spare
@@ -518,7 +533,11 @@ int encode_range(rcx_ctx* c, int coder, const void* d_src, u64 n, u32 block, voi
         hipLaunchKernelGGL(rcx_scatter_k, dim3((u32)nblocks), dim3(256), 0, s, v.slots, slot, v.sizes, d_offsets,
                            static_cast<u8*>(d_dst), dst_cap, is_rans(coder) ? static_cast<const u32*>(v.starts) : static_cast<const u32*>(nullptr));
     }
-    return hipGetLastError() == hipSuccess ? RCX_OK : RCX_E_HIP;
+    {
+        const hipError_t last = hipGetLastError();
+        if (last != hipSuccess && getenv("RCX_DEBUG")) fprintf(stderr, "rcx: encode launches left %s\n", hipGetErrorString(last));
+        return last == hipSuccess ? RCX_OK : RCX_E_HIP;
+    }
 }
 
 } // namespace
@@ -535,7 +554,7 @@ int rcx_decode_blocks_device(rcx_ctx* c, int coder, const void* d_comp, uint64_t
     if (nblocks == 0) return RCX_OK;
     if (nblocks > 0x7FFFFFFFull) return RCX_E_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(rcx_enter_device(c->device));
     if (!is_rans(coder)) {
         int r = ensure_divtab(c, block);
         if (r != RCX_OK) return r;
@@ -647,7 +666,7 @@ int rcx_encode_blocks(rcx_ctx* c, int coder, const uint8_t* src, uint64_t n, uin
                       uint8_t* dst, uint64_t dst_cap, uint64_t* dst_size, uint64_t* offsets)
 {
     if (!c || !block_ok(block) || !dst_size || (n && (!src || !dst))) return RCX_E_ARG;
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(rcx_enter_device(c->device));
     *dst_size = 0;
     if (!coder_ok(coder)) return RCX_E_ARG;
     const u64 nblocks = rcx_block_count(n, block);
@@ -716,6 +735,7 @@ int rcx_encode_blocks(rcx_ctx* c, int coder, const uint8_t* src, uint64_t n, uin
     job.caller_out = dst;
     r = host_run(c, p, job);
     const int latched = rcx_ctx_sync_status(c, nullptr, nullptr);
+    if (getenv("RCX_DEBUG") && (r != RCX_OK || latched != RCX_OK)) fprintf(stderr, "rcx: host encode: pipeline %d, latched status %d\n", r, latched);
     if (r != RCX_OK) return r;
     if (latched != RCX_OK) return latched;
     *dst_size = running;
@@ -729,7 +749,7 @@ int rcx_decode_blocks(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
 {
     if (!c || !block_ok(block) || !dst_size || (nblocks && (!comp || !offsets || !dst))) return RCX_E_ARG;
     if (!coder_ok(coder) || nblocks > 0x7FFFFFFFull) return RCX_E_ARG;
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(rcx_enter_device(c->device));
     *dst_size = 0;
     if (nblocks == 0) return RCX_OK;
     if (offsets[nblocks] > comp_size || offsets[nblocks] < offsets[nblocks - 1] || offsets[nblocks] - offsets[nblocks - 1] < 4)
@@ -809,7 +829,7 @@ int rcx_stream_encode(rcx_ctx* c, int coder, const uint8_t* src, uint32_t n,
 {
     if (!c || !dst || !dst_size || (n && !src)) return RCX_E_ARG;
     if (!coder_ok(coder) || n > RCX_MAX_STREAM) return RCX_E_ARG;
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(rcx_enter_device(c->device));
     *dst_size = 0;
     if (request_size) *request_size = 0;
     if (is_rans(coder)) {
@@ -932,7 +952,7 @@ int rcx_stream_decode(rcx_ctx* c, int coder, const uint8_t* comp, uint64_t comp_
 {
     if (!c || !dst || !dst_size || (comp_size && !comp)) return RCX_E_ARG;
     if (!coder_ok(coder) || comp_size > 0xFFFFFFFFull) return RCX_E_ARG;
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(rcx_enter_device(c->device));
     *dst_size = 0;
     if (request_size) *request_size = 0;
     if (is_rans(coder)) {
@@ -1109,7 +1129,7 @@ int rcx_dstream_create(rcx_ctx* c, rcx_dstream** out)
 {
     if (!c || !out) return RCX_E_ARG;
     *out = nullptr;
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(rcx_enter_device(c->device));
     rcx_dstream* d = new (std::nothrow) rcx_dstream();
     if (!d) return RCX_E_NOMEM;
     d->ctx = c;
@@ -1144,7 +1164,7 @@ int rcx_dstream_decode(rcx_dstream* d, const uint8_t* bytes, uint64_t size, uint
     *produced_now = 0;
     if (request_size) *request_size = 0;
     if (d->finished) return RCX_OK;
-    HIP_TRY(hipSetDevice(d->ctx->device));
+    HIP_TRY(rcx_enter_device(d->ctx->device));
     if (d->in_bytes == 0 && size < 8) { // cpprcoder.h:877-880: State_Init wants its 8 bytes in one call and keeps nothing
         if (request_size) *request_size = 8;
         return RCX_PENDING;
@@ -1223,7 +1243,7 @@ int rcx_estream_create(rcx_ctx* c, uint32_t declared, rcx_estream** out)
 {
     if (!c || !out || declared > RCX_MAX_STREAM) return RCX_E_ARG;
     *out = nullptr;
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(rcx_enter_device(c->device));
     rcx_estream* e = new (std::nothrow) rcx_estream();
     if (!e) return RCX_E_NOMEM;
     e->ctx = c;
@@ -1273,7 +1293,7 @@ int rcx_estream_encode(rcx_estream* e, const uint8_t* bytes, uint64_t size, uint
         return RCX_PENDING;
     }
     if (size > (u64)(e->declared - e->consumed)) return RCX_E_ARG; // CPPRCODER_ASSERT, cpprcoder.h:700
-    HIP_TRY(hipSetDevice(e->ctx->device));
+    HIP_TRY(rcx_enter_device(e->ctx->device));
     // what this call may change, kept for rcx_estream_rewind: the state, and the stream from the first byte the reference
     // has not written yet (a carry stops there) to a little past what is in memory
     {
@@ -1354,7 +1374,7 @@ int rcx_estream_encode(rcx_estream* e, const uint8_t* bytes, uint64_t size, uint
 int rcx_estream_rewind(rcx_estream* e)
 {
     if (!e || !e->have_backup) return RCX_E_ARG;
-    HIP_TRY(hipSetDevice(e->ctx->device));
+    HIP_TRY(rcx_enter_device(e->ctx->device));
     HIP_TRY(hipMemcpy(e->state, e->backup, sizeof(RcxEState), hipMemcpyDeviceToDevice));
     if (e->tail_bytes) HIP_TRY(hipMemcpy(e->slot + e->tail_from, e->tail_backup, e->tail_bytes, hipMemcpyDeviceToDevice));
     e->consumed = e->backup_consumed;
@@ -1393,7 +1413,7 @@ int rcx_ctx_last_redo(rcx_ctx* c, uint64_t nblocks, uint64_t* count)
     *count = 0;
     if (nblocks == 0 || !c->redo) return RCX_OK;
     if (nblocks > c->redo_count) return RCX_E_ARG;
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(rcx_enter_device(c->device));
     HIP_TRY(hipDeviceSynchronize());
     std::vector<u32> host(nblocks);
     HIP_TRY(hipMemcpy(host.data(), c->redo, nblocks * sizeof(u32), hipMemcpyDeviceToHost));
@@ -1426,7 +1446,7 @@ uint64_t rcx_bwt_decoded_size(uint64_t n)
 int rcx_bwt_reserve(rcx_ctx* c, uint64_t n)
 {
     if (!c) return RCX_E_ARG;
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(rcx_enter_device(c->device));
     if (!c->bwt_lds_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcx_bwt_fwd_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCX_BWT_FWD_LDS));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcx_bwt_fwd_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCX_BWT_FWD_LDS));
@@ -1521,7 +1541,7 @@ namespace
 int bwt_host(rcx_ctx* c, bool forward, const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t dst_cap, uint64_t* dst_size)
 {
     if (!c || !dst_size || (n && (!src || !dst))) return RCX_E_ARG;
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(rcx_enter_device(c->device));
     const u64 out = forward ? rcx_bwt_encode_bound(n) : rcx_bwt_decoded_size(n);
     *dst_size = out;
     if (out > dst_cap) return RCX_E_CAPACITY;
@@ -1603,7 +1623,7 @@ int rcx_bwt_last_ties(rcx_ctx* c, uint64_t* count)
         *count = c->pipe->bwt_ties;
         return RCX_OK;
     }
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(rcx_enter_device(c->device));
     HIP_TRY(hipDeviceSynchronize());
     u32 v = 0;
     HIP_TRY(hipMemcpy(&v, c->ties, sizeof(u32), hipMemcpyDeviceToHost));
@@ -1621,7 +1641,7 @@ int rcx_ctx_set_timing(rcx_ctx* c, int enabled)
 int rcx_ctx_get_timing(rcx_ctx* c, double* ms, uint64_t* launches, int reset)
 {
     if (!c) return RCX_E_ARG;
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(rcx_enter_device(c->device));
     for (auto& p : c->pending) {
         float t = 0.f;
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) {

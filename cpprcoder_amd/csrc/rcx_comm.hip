@@ -140,6 +140,7 @@ int rcx_allgatherv_segments(rcx_comm* c, const void* d_segment, const uint64_t* 
 {
     if (!c || !d_offsets || !d_concat || (nblocks && !d_segment)) return RCX_E_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    (void)hipGetLastError(); // (what an earlier call of this thread left behind is not this call's: see rcx_enter_device in rcx_api.hip)
     HIP_TRY(hipSetDevice(c->device));
     const int n = c->nranks;
     // 1. what does every rank bring?  (the one host synchronisation of the exchange: send and receive counts are

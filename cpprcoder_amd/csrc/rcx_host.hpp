@@ -123,6 +123,7 @@ int host_pipe_get(rcx_ctx* c, HostPipe** out)
     }
     for (int t = 0; t < p->feeders; ++t) ok = ok && hipStreamCreateWithFlags(&p->in_streams[t], hipStreamNonBlocking) == hipSuccess;
     if (!ok) {
+        if (getenv("RCX_DEBUG")) fprintf(stderr, "rcx_host: could not make the pipe's streams (last HIP error: %s)\n", hipGetErrorString(hipGetLastError()));
         host_pipe_destroy(p);
         return RCX_E_HIP;
     }
@@ -204,8 +205,9 @@ struct HostRun {
         marks.push_back(Mark{what, thread, chunk, piece, ms});
     }
 
-    void fail(int e)
+    void fail(int e, const char* where = "")
     {
+        if (getenv("RCX_DEBUG")) fprintf(stderr, "rcx_host: stage failed with %d %s (last HIP error: %s)\n", e, where, hipGetErrorString(hipGetLastError()));
         std::lock_guard<std::mutex> g(m);
         if (err == RCX_OK) err = e;
         cv.notify_all();
@@ -277,7 +279,7 @@ void host_feeder(HostRun* r, int t)
         }
     }
     if (ok) ok = landed();
-    if (!ok) r->fail(RCX_E_HIP);
+    if (!ok) r->fail(RCX_E_HIP, "in a feeder");
 }
 
 // A drainer: waits (on the host) for a chunk's last launch, then brings every movers-th piece of its output back.
@@ -312,7 +314,7 @@ void host_drainer(HostRun* r, int t)
             if (r->err != RCX_OK) break;
         }
         if (hipEventSynchronize(r->done[k]) != hipSuccess) {
-            r->fail(RCX_E_HIP);
+            r->fail(RCX_E_HIP, "waiting for a chunk's launches");
             break;
         }
         r->mark("done", t, k, 0);
@@ -353,7 +355,7 @@ void host_drainer(HostRun* r, int t)
     if (ok && !staged) ok = hipStreamSynchronize(s) == hipSuccess;
     for (auto& e : there)
         if (e) (void)hipEventDestroy(e);
-    if (!ok) r->fail(RCX_E_HIP);
+    if (!ok) r->fail(RCX_E_HIP, "in a drainer");
 }
 
 // Runs a job.  Returns the first error of any stage; the device is idle on return either way.
@@ -398,7 +400,10 @@ int host_run(rcx_ctx* c, HostPipe* p, const HostJob& job)
     r.in_first_piece[K] = pieces;
     std::vector<hipEvent_t> began(r.trace ? K : 0, nullptr); // (trace: when the device started on a chunk's launches)
     for (u64 k = 0; k < K; ++k) {
-        if (hipEventCreateWithFlags(&r.done[k], r.trace ? hipEventDefault : hipEventDisableTiming) != hipSuccess) rc = RCX_E_HIP;
+        if (hipEventCreateWithFlags(&r.done[k], r.trace ? hipEventDefault : hipEventDisableTiming) != hipSuccess) {
+            if (getenv("RCX_DEBUG")) fprintf(stderr, "rcx_host: could not make an event (last HIP error: %s)\n", hipGetErrorString(hipGetLastError()));
+            rc = RCX_E_HIP;
+        }
         if (r.trace && hipEventCreate(&began[k]) != hipSuccess) rc = RCX_E_HIP;
     }
     std::vector<std::thread> threads;
@@ -420,7 +425,7 @@ int host_run(rcx_ctx* c, HostPipe* p, const HostJob& job)
             if (e == RCX_OK && hipEventRecord(r.done[k], s) != hipSuccess) e = RCX_E_HIP;
             r.mark("launch<", -1, k, 0);
             if (e != RCX_OK) {
-                r.fail(e);
+                r.fail(e, "launching a chunk");
                 break;
             }
             std::lock_guard<std::mutex> g(r.m);

@@ -177,3 +177,37 @@ def test_chunked_block_sort(monkeypatch, data, oracle, mode):
         assert np.array_equal(enc[3077 * 32770: m], src[3077 * 32768:])
     finally:
         ctx.close()
+
+
+def test_an_error_left_behind_by_another_hip_call_is_not_reported(data):
+    """Since HIP 7 an error code returned by any runtime call stays in the calling thread's "last error" until it is read.  The
+    library checks its kernel launches by reading it, so it clears it on entry: an error some earlier call of the thread left
+    behind (here: a hipFree of nonsense) must not turn up as RCX_E_HIP of the next encode."""
+    import ctypes as C
+    from cpprcoder_amd import rcx
+    rcx.lib()
+    path = next((line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line), None)
+    assert path, "the HIP runtime should be loaded by now"
+    hip = C.CDLL(path)
+    hip.hipFree.argtypes, hip.hipFree.restype = [C.c_void_p], C.c_int
+    assert hip.hipFree(C.c_void_p(0x1234)) != 0  # an error that nobody reads
+    ctx = rcx.Context(0)
+    try:
+        part = data[: 3 * (16 << 20) + 99]
+        dst, size, offsets, back = host_round_trip(ctx, part, BLOCK, rcx.CODER_ADAPTIVE)
+        assert np.array_equal(back, part)
+        # the device-pointer calls likewise (the tensors are made first: torch reads the thread's last error too, and would
+        # report the one provoked here as its own)
+        src = torch.from_numpy(part).cuda()
+        out = torch.zeros(rcx.encode_bound(len(part), BLOCK), dtype=torch.uint8, device="cuda")
+        offs = torch.zeros(rcx.block_count(len(part), BLOCK) + 1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        assert hip.hipFree(C.c_void_p(0x1234)) != 0
+        ctx.encode_blocks_device(src, BLOCK, out, offs)
+        ctx.sync_status()
+        hip.hipGetLastError.restype = C.c_int
+        hip.hipGetLastError()  # (nothing of ours should be there; whatever is, is not left for torch to find)
+        total = int(offs[-1])
+        assert total == size and np.array_equal(out[:total].cpu().numpy(), dst[:size])
+    finally:
+        ctx.close()
