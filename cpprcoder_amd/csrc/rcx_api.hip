@@ -113,12 +113,12 @@ struct Timed {
             return;
         }
         p.what = what;
-        hipEventRecord(p.a, s);
+        (void)hipEventRecord(p.a, s);
     }
     ~Timed()
     {
         if (!on) return;
-        hipEventRecord(p.b, s);
+        (void)hipEventRecord(p.b, s);
         c->pending.push_back(p);
     }
 };

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
         for (u32 q = 0; q < 17; ++q) leaves[q * 16] = v; // 16 nodes + the scratch row
     }
     u32 U1 = 64u * j + 16, U2 = U1 + 16, U3 = U1 + 32, U4_ = U1 + 48;
-    const u32 T0 = 4u * j, T1 = T0 + 1, T2 = T0 + 2, T3 = T0 + 3;
+    const u32 T0 = 4u * j;
     const u32 m1 = (j & 1u) ? ~0u : 0u, m2 = (j & 2u) ? ~0u : 0u;
 
     QuadInput in;
@@ -340,6 +340,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
     // LDS and global accesses stay with the compiler (and its s_waitcnt placement).
     const u32 T0p3 = T0 + 3;
     const u32 leaves_lds = (u32)reinterpret_cast<uintptr_t>(leaves); // low half of a flat LDS address = the LDS offset
+    const u32 ring_lds = (u32)reinterpret_cast<uintptr_t>(block_ring);
 #if defined(RCX_STAMP_DEC) /* diagnostic build only (tools/diag/stamp_quad.py): where does one symbol's time go? */
 #define RCX_QUAD_STAMP(i) if (stamp_now_) stamp_t_[stamp_at_ + (i)] = __builtin_amdgcn_s_memtime();
 #else
@@ -359,66 +360,74 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
         const u32 a1_ = rcx_mul24(U1, t_), a2_ = rcx_mul24(U2, t_), a3_ = rcx_mul24(U3, t_);               \
         const u32 a4_ = rcx_mul24(U4_, t_);                                                                \
         u32 node_, rem_, ro_, la_, x1_, x2_, x3_, x4_;                                                     \
-        u64 c1_, c2_, c3_, c4_;                                                                            \
+        u64 c1_, c2_, c3_, c4_, cz_;                                                                       \
         asm volatile("v_sub_co_u32_e64 %[x1], %[c1], %[low], %[a1]\n\t"                                    \
                      "v_sub_co_u32_e64 %[x2], %[c2], %[low], %[a2]\n\t"                                    \
                      "v_sub_co_u32_e64 %[x3], %[c3], %[low], %[a3]\n\t"                                    \
                      "v_sub_co_u32_e64 %[x4], %[c4], %[low], %[a4]\n\t"                                    \
-                     "v_subb_co_u32_e64 %[nd], %[c1], 4, 0, %[c1]\n\t"                                     \
-                     "v_min3_u32 %[rm], %[x1], %[x2], %[x3]\n\t"                                           \
-                     "v_subb_co_u32_e64 %[nd], %[c2], %[nd], 0, %[c2]\n\t"                                 \
-                     "v_min3_u32 %[rm], %[rm], %[x4], %[low]\n\t"                                          \
-                     "v_subb_co_u32_e64 %[nd], %[c3], %[nd], 0, %[c3]\n\t"                                 \
-                     "v_subb_co_u32_e64 %[nd], %[c4], %[nd], 0, %[c4]\n\t"                                 \
-                     "v_min_u32_dpp %[rm], %[rm], %[rm] " RCX_QP1                                          \
+                     "v_subb_co_u32_e64 %[nd], %[cz], 4, 0, %[c1]\n\t" /* (the borrows stay: the update below) */ \
+                     "v_subb_co_u32_e64 %[nd], %[cz], %[nd], 0, %[c2]\n\t"                                 \
+                     "v_subb_co_u32_e64 %[nd], %[cz], %[nd], 0, %[c3]\n\t"                                 \
+                     "v_subb_co_u32_e64 %[nd], %[cz], %[nd], 0, %[c4]\n\t"                                 \
                      "v_add_u32 %[bp], %[bp], %[k8]\n\t" /* the stream position moves on */                \
-                     "v_add_u32_dpp %[nd], %[nd], %[nd] " RCX_QP1                                          \
-                     "v_min_u32_dpp %[rm], %[rm], %[rm] " RCX_QP2                                          \
-                     "v_bfe_u32 %[ro], %[bp], 5, 5\n\t" /* ring slot of the next pair */                   \
+                     "v_bfe_u32 %[ro], %[bp], 5, 5\n\t" /* ring slot of the next pair ... */               \
+                     "v_lshl_add_u32 %[ro], %[ro], 2, %[rb]" /* ... and its LDS address (formed here: a vector instruction right \
+                                                               behind the sequence that reads a register of it costs an s_nop) */ \
+                     : [nd] "=&v"(node_), [ro] "=&v"(ro_), [bp] "+v"(in.bp8),                               \
+                       [x1] "=&v"(x1_), [x2] "=&v"(x2_), [x3] "=&v"(x3_), [x4] "=&v"(x4_),                 \
+                       [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_), [c4] "=&s"(c4_), [cz] "=&s"(cz_) \
+                     : [low] "v"(in.low), [a1] "v"(a1_), [a2] "v"(a2_), [a3] "v"(a3_), [a4] "v"(a4_),      \
+                       [k8] "v"(k8_), [rb] "v"(ring_lds));                                                 \
+        {                                                                                                  \
+            const RcxLdsU32* at_ = reinterpret_cast<const RcxLdsU32*>(ro_); /* the stream bytes of the next symbol: asked for first, used in the shadow of the leaf read */ \
+            in.w0 = at_[0];                                                                                \
+            in.w1 = at_[1];                                                                                \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        /* the node index first (the leaf read waits for it); the remainder's steps across the quad go behind the read */ \
+        asm volatile("v_add_u32_dpp %[nd], %[nd], %[nd] " RCX_QP1                                          \
+                     "v_min3_u32 %[rm], %[x1], %[x2], %[x3]\n\t"                                           \
+                     "v_min3_u32 %[rm], %[rm], %[x4], %[low]\n\t"                                          \
                      "v_add_u32_dpp %[nd], %[nd], %[nd] " RCX_QP2                                          \
                      "v_lshl_add_u32 %[la], %[nd], 8, %[lvb]" /* LDS address of the lane's 4 counts of the node */ \
-                     : [nd] "=&v"(node_), [rm] "=&v"(rem_), [ro] "=&v"(ro_), [bp] "+v"(in.bp8), [la] "=&v"(la_), \
-                       [x1] "=&v"(x1_), [x2] "=&v"(x2_), [x3] "=&v"(x3_), [x4] "=&v"(x4_),                 \
-                       [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_), [c4] "=&s"(c4_)                  \
-                     : [low] "v"(in.low), [a1] "v"(a1_), [a2] "v"(a2_), [a3] "v"(a3_), [a4] "v"(a4_),      \
-                       [k8] "v"(k8_), [lvb] "v"(leaves_lds));                                              \
+                     : [nd] "+v"(node_), [rm] "=&v"(rem_), [la] "=&v"(la_)                                  \
+                     : [low] "v"(in.low), [x1] "v"(x1_), [x2] "v"(x2_), [x3] "v"(x3_), [x4] "v"(x4_),      \
+                       [lvb] "v"(leaves_lds));                                                             \
         /* round 2: which of the node's 16 symbols */                                                      \
         RCX_QUAD_STAMP(0);                                                                                 \
         const RcxV4 l_ = *reinterpret_cast<const RcxLdsV4*>(la_);                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
-        {                                                                                                  \
-            const u32* at_ = in.ring + ro_; /* for the next symbol: never waited for */                    \
-            in.w0 = at_[0];                                                                                \
-            in.w1 = at_[1];                                                                                \
-        }                                                                                                  \
-        /* meanwhile cpprcoder.h:1134-1177: +1 on every cumulative sum above the node */                   \
+        /* meanwhile cpprcoder.h:1134-1177: +1 on every cumulative sum above the node -- the bounds whose      \
+           subtraction borrowed in round 1 (bound above low <=> its node number above the symbol's node); a     \
+           target past the total leaves no borrow and raises none, as find()'s fall-through needs it */       \
         u32 sb_;                                                                                           \
-        asm volatile("v_cmp_lt_u32_e64 %[c1], %[n], %[t1]\n\t"                                             \
-                     "v_cmp_lt_u32_e64 %[c2], %[n], %[t2]\n\t"                                             \
-                     "v_cmp_lt_u32_e64 %[c3], %[n], %[t3]\n\t"                                             \
-                     "v_cmp_le_u32_e64 %[c4], %[n], %[t3]\n\t"                                             \
+        asm volatile("v_min_u32_dpp %[rm], %[rm], %[rm] " RCX_QP1                                          \
                      "v_addc_co_u32_e64 %[u1], %[c1], 0, %[u1], %[c1]\n\t"                                 \
                      "v_addc_co_u32_e64 %[u2], %[c2], 0, %[u2], %[c2]\n\t"                                 \
+                     "v_min_u32_dpp %[rm], %[rm], %[rm] " RCX_QP2                                          \
                      "v_addc_co_u32_e64 %[u3], %[c3], 0, %[u3], %[c3]\n\t"                                 \
                      "v_addc_co_u32_e64 %[u4], %[c4], 0, %[u4], %[c4]\n\t"                                 \
                      "v_lshl_add_u32 %[sb], %[n], 4, %[t0p3]" /* symbol, if none of the lane's bounds is above */ \
-                     : [u1] "+v"(U1), [u2] "+v"(U2), [u3] "+v"(U3), [u4] "+v"(U4_),                         \
-                       [sb] "=&v"(sb_), [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_), [c4] "=&s"(c4_) \
-                     : [n] "v"(node_), [t1] "v"(T1), [t2] "v"(T2), [t3] "v"(T3), [t0p3] "v"(T0p3));        \
+                     : [u1] "+v"(U1), [u2] "+v"(U2), [u3] "+v"(U3), [u4] "+v"(U4_), [rm] "+v"(rem_),        \
+                       [sb] "=&v"(sb_), [c1] "+s"(c1_), [c2] "+s"(c2_), [c3] "+s"(c3_), [c4] "+s"(c4_)     \
+                     : [n] "v"(node_), [t0p3] "v"(T0p3));                                                  \
+        asm volatile("v_alignbit_b32 %[n4], %[w1], %[w0], %[bp]\n\t" /* the 4 bytes at bp8 ... */           \
+                     "v_perm_b32 %[n4], %[n4], %[n4], %[swap]"      /* ... first one on top */              \
+                     : [n4] "=&v"(in.n4)                                                                   \
+                     : [w0] "v"(in.w0), [w1] "v"(in.w1), [bp] "v"(in.bp8), [swap] "s"(0x00010203u));       \
         u32 lo_, rg_, sym_, own_, q2_, q3_, q4_, qa_, qb_, qc_, qe_, tot_, pre_, o2_, d2_, ya_, yb_, yc_, ye_, hi_; \
         asm volatile("v_add_u32 %[q2], %[lx], %[ly]\n\t"                                                   \
                      "v_add_u32 %[q3], %[q2], %[lz]\n\t"                                                   \
                      "v_add_u32 %[q4], %[q3], %[lw]\n\t"                                                   \
+                     "v_mul_u32_u24 %[qe], %[q4], %[t]\n\t"                                                \
                      "v_mul_u32_u24 %[qa], %[lx], %[t]\n\t"                                                \
                      "v_mul_u32_u24 %[qb], %[q2], %[t]\n\t"                                                \
-                     "v_add_u32_dpp %[tot], %[q4], %[q4] " RCX_QP1                                         \
-                     "v_and_b32_dpp %[pre], %[q4], %[m1] " RCX_QP1                                         \
+                     "v_add_u32_dpp %[tot], %[qe], %[qe] " RCX_QP1 /* the lanes' sums are scanned scaled: (a+b)t = at+bt */ \
+                     "v_and_b32_dpp %[pre], %[qe], %[m1] " RCX_QP1                                         \
                      "v_mul_u32_u24 %[qc], %[q3], %[t]\n\t"                                                \
-                     "v_mul_u32_u24 %[qe], %[q4], %[t]\n\t"                                                \
+                     "v_sub_u32 %[d2], %[rem], %[pre]\n\t"                                                 \
                      "v_and_b32_dpp %[o2], %[tot], %[m2] " RCX_QP2                                         \
-                     "v_add_u32 %[pre], %[pre], %[o2]\n\t"   /* counts of the node's symbols in lower lanes */ \
-                     "v_mul_u32_u24 %[o2], %[pre], %[t]\n\t"                                               \
-                     "v_sub_u32 %[d2], %[rem], %[o2]\n\t"                                                  \
+                     "v_sub_u32 %[d2], %[d2], %[o2]\n\t"     /* rem - t x the counts of the node's symbols in lower lanes */ \
                      "v_sub_co_u32_e64 %[ya], %[c1], %[d2], %[qa]\n\t"                                     \
                      "v_sub_co_u32_e64 %[yb], %[c2], %[d2], %[qb]\n\t"                                     \
                      "v_sub_co_u32_e64 %[yc], %[c3], %[d2], %[qc]\n\t"                                     \
@@ -438,19 +447,15 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
                      "v_cndmask_b32_e64 %[ye], 0, %[sym], %[c4]\n\t"                                       \
                      "v_sub_u32 %[rg], %[lo], %[hi]\n\t"                                                   \
                      "v_lshl_or_b32 %[word], %[ye], %[sh], %[word]\n\t"                                    \
-                     "v_alignbit_b32 %[n4], %[w1], %[w0], %[bp]\n\t" /* the 4 bytes at bp8 ... */           \
-                     "v_perm_b32 %[n4], %[n4], %[n4], %[swap]\n\t" /* ... first one on top */              \
                      "v_and_b32 %[ye], 3, %[sym]\n\t"                                                      \
                      "v_lshl_add_u32 %[ye], %[ye], 2, %[la]"         /* LDS address of the symbol's count */ \
                      : [lo] "=&v"(lo_), [rg] "=&v"(rg_), [sym] "=&v"(sym_), [own] "=&v"(own_), [q2] "=&v"(q2_), \
                        [q3] "=&v"(q3_), [q4] "=&v"(q4_), [qa] "=&v"(qa_), [qb] "=&v"(qb_), [qc] "=&v"(qc_),  \
                        [qe] "=&v"(qe_), [tot] "=&v"(tot_), [pre] "=&v"(pre_), [o2] "=&v"(o2_), [d2] "=&v"(d2_), \
                        [ya] "=&v"(ya_), [yb] "=&v"(yb_), [yc] "=&v"(yc_), [ye] "=&v"(ye_), [hi] "=&v"(hi_),  \
-                       [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_), [c4] "=&s"(c4_), [word] "+v"(WORD), \
-                       [n4] "=&v"(in.n4)                                                                   \
+                       [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_), [c4] "=&s"(c4_), [word] "+v"(WORD)  \
                      : [lx] "v"(l_.x), [ly] "v"(l_.y), [lz] "v"(l_.z), [lw] "v"(l_.w), [t] "v"(t_),        \
                        [rem] "v"(rem_), [m1] "v"(m1), [m2] "v"(m2), [sb] "v"(sb_), [sh] "n"(SHIFT),        \
-                       [w0] "v"(in.w0), [w1] "v"(in.w1), [bp] "v"(in.bp8), [swap] "s"(0x00010203u),        \
                        [la] "v"(la_));                                                                     \
         RCX_QUAD_STAMP(1);                                                                                 \
         in.low = lo_;   /* :906 */                                                                         \

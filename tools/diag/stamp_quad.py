@@ -1,6 +1,6 @@
 """Where one symbol of rcx_dec_quad_k spends its time (diagnostic build: -DRCX_STAMP_DEC, see README).
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DRCX_STAMP_DEC -o build/abl/librcx_stampdec.so cpprcoder_amd/csrc/rcx_api.hip
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DRCX_STAMP_DEC -o build/abl/librcx_stampdec.so cpprcoder_amd/csrc/rcx_api.hip cpprcoder_amd/csrc/rcx_comm.hip -L/opt/rocm/lib -lrccl
     RCX_LIBRARY=build/abl/librcx_stampdec.so python tools/diag/stamp_quad.py
 """
 import ctypes as C, os, sys, torch
