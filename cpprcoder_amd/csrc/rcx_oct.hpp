@@ -348,7 +348,22 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
 #endif
 #define RCX_QP1 "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
 #define RCX_QP2 "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-#define RCX_QUAD_DEC_SYMBOL(K, WORD, SHIFT)                                                                   \
+// What a symbol leaves for the one behind it (below): its number (valid in the lane that owns it), that lane's mask, and
+// the LDS address of the lane's four counts of the node.
+    u32 p_sym_ = 0, p_la_ = leaves_lds;
+    u64 p_own_ = 0;
+// One symbol.  Its byte and the +1 on its count are NOT made here but by the next symbol (HP = 1: PWORD, PSHIFT are that
+// earlier symbol's word and bit position) or by RCX_QUAD_DEC_FINISH: nothing the coder state needs depends on them, so
+// they fill the slots the node index's steps across the quad need anyway (the ds_add still comes before the next leaf
+// read: LDS serves a wave's operations in order) and the wait for the leaf read.
+#define RCX_QD_PREV_A_0 "s_nop 1\n\t"
+#define RCX_QD_PREV_A_1 "v_cndmask_b32_e64 %[pown], 0, 1, %[pc]\n\t"                                                \
+                        "v_and_b32 %[pad], 3, %[psym]\n\t"                                                         \
+                        "v_lshl_add_u32 %[pad], %[pad], 2, %[pla]\n\t" /* LDS address of the earlier symbol's count */
+#define RCX_QD_PREV_S_0
+#define RCX_QD_PREV_S_1 "\n\tv_cndmask_b32_e64 %[pye], 0, %[psym], %[pc]\n\t"                                       \
+                        "v_lshl_or_b32 %[pword], %[pye], %[psh], %[pword]"
+#define RCX_QUAD_DEC_SYMBOL(K, HP, PWORD, PSHIFT)                                                           \
     {                                                                                                      \
         /* cpprcoder.h:926-940 (in.n4 = the next four stream bytes, ready since the previous symbol) */    \
         const u32 k8_ = rcx_clz(in.range) & 0x18u;                                                         \
@@ -359,7 +374,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
         /* round 1: which of the 16 nodes.  node = bounds at or below low, rem = low - the largest */      \
         const u32 a1_ = rcx_mul24(U1, t_), a2_ = rcx_mul24(U2, t_), a3_ = rcx_mul24(U3, t_);               \
         const u32 a4_ = rcx_mul24(U4_, t_);                                                                \
-        u32 node_, rem_, ro_, la_, x1_, x2_, x3_, x4_;                                                     \
+        u32 node_, rem_, ro_, la_, x1_, x2_, x3_, x4_, pown_, pad_, pye_;                                  \
         u64 c1_, c2_, c3_, c4_, cz_;                                                                       \
         asm volatile("v_sub_co_u32_e64 %[x1], %[c1], %[low], %[a1]\n\t"                                    \
                      "v_sub_co_u32_e64 %[x2], %[c2], %[low], %[a2]\n\t"                                    \
@@ -369,53 +384,59 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
                      "v_subb_co_u32_e64 %[nd], %[cz], %[nd], 0, %[c2]\n\t"                                 \
                      "v_subb_co_u32_e64 %[nd], %[cz], %[nd], 0, %[c3]\n\t"                                 \
                      "v_subb_co_u32_e64 %[nd], %[cz], %[nd], 0, %[c4]\n\t"                                 \
+                     RCX_QD_PREV_A_##HP                                                                    \
+                     : [nd] "=&v"(node_), [x1] "=&v"(x1_), [x2] "=&v"(x2_), [x3] "=&v"(x3_), [x4] "=&v"(x4_), \
+                       [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_), [c4] "=&s"(c4_), [cz] "=&s"(cz_), \
+                       [pown] "=&v"(pown_), [pad] "=&v"(pad_)                                              \
+                     : [low] "v"(in.low), [a1] "v"(a1_), [a2] "v"(a2_), [a3] "v"(a3_), [a4] "v"(a4_),      \
+                       [pc] "s"(p_own_), [psym] "v"(p_sym_), [pla] "v"(p_la_));                            \
+        if (HP) (void)__hip_atomic_fetch_add(reinterpret_cast<RcxLdsU32*>(pad_), pown_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); /* :916, the earlier symbol's */ \
+        asm volatile("v_add_u32_dpp %[nd], %[nd], %[nd] " RCX_QP1                                          \
                      "v_add_u32 %[bp], %[bp], %[k8]\n\t" /* the stream position moves on */                \
-                     "v_bfe_u32 %[ro], %[bp], 5, 5\n\t" /* ring slot of the next pair ... */               \
+                     "v_bfe_u32 %[ro], %[bp], 5, 5\n\t"  /* ring slot of the next pair ... */               \
                      "v_lshl_add_u32 %[ro], %[ro], 2, %[rb]" /* ... and its LDS address (formed here: a vector instruction right \
                                                                behind the sequence that reads a register of it costs an s_nop) */ \
-                     : [nd] "=&v"(node_), [ro] "=&v"(ro_), [bp] "+v"(in.bp8),                               \
-                       [x1] "=&v"(x1_), [x2] "=&v"(x2_), [x3] "=&v"(x3_), [x4] "=&v"(x4_),                 \
-                       [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_), [c4] "=&s"(c4_), [cz] "=&s"(cz_) \
-                     : [low] "v"(in.low), [a1] "v"(a1_), [a2] "v"(a2_), [a3] "v"(a3_), [a4] "v"(a4_),      \
-                       [k8] "v"(k8_), [rb] "v"(ring_lds));                                                 \
+                     : [nd] "+v"(node_), [ro] "=&v"(ro_), [bp] "+v"(in.bp8)                                 \
+                     : [k8] "v"(k8_), [rb] "v"(ring_lds));                                                 \
         {                                                                                                  \
-            const RcxLdsU32* at_ = reinterpret_cast<const RcxLdsU32*>(ro_); /* the stream bytes of the next symbol: asked for first, used in the shadow of the leaf read */ \
+            const RcxLdsU32* at_ = reinterpret_cast<const RcxLdsU32*>(ro_); /* the stream bytes of the next symbol */ \
             in.w0 = at_[0];                                                                                \
             in.w1 = at_[1];                                                                                \
         }                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
-        /* the node index first (the leaf read waits for it); the remainder's steps across the quad go behind the read */ \
-        asm volatile("v_add_u32_dpp %[nd], %[nd], %[nd] " RCX_QP1                                          \
-                     "v_min3_u32 %[rm], %[x1], %[x2], %[x3]\n\t"                                           \
-                     "v_min3_u32 %[rm], %[rm], %[x4], %[low]\n\t"                                          \
-                     "v_add_u32_dpp %[nd], %[nd], %[nd] " RCX_QP2                                          \
+        asm volatile("v_add_u32_dpp %[nd], %[nd], %[nd] " RCX_QP2                                          \
                      "v_lshl_add_u32 %[la], %[nd], 8, %[lvb]" /* LDS address of the lane's 4 counts of the node */ \
-                     : [nd] "+v"(node_), [rm] "=&v"(rem_), [la] "=&v"(la_)                                  \
-                     : [low] "v"(in.low), [x1] "v"(x1_), [x2] "v"(x2_), [x3] "v"(x3_), [x4] "v"(x4_),      \
-                       [lvb] "v"(leaves_lds));                                                             \
+                     : [nd] "+v"(node_), [la] "=&v"(la_)                                                    \
+                     : [lvb] "v"(leaves_lds));                                                             \
         /* round 2: which of the node's 16 symbols */                                                      \
         RCX_QUAD_STAMP(0);                                                                                 \
         const RcxV4 l_ = *reinterpret_cast<const RcxLdsV4*>(la_);                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
-        /* meanwhile cpprcoder.h:1134-1177: +1 on every cumulative sum above the node -- the bounds whose      \
-           subtraction borrowed in round 1 (bound above low <=> its node number above the symbol's node); a     \
-           target past the total leaves no borrow and raises none, as find()'s fall-through needs it */       \
+        /* behind the read: the remainder (round 1's other result) across the quad; cpprcoder.h:1134-1177, +1 on every \
+           cumulative sum above the node -- the bounds whose subtraction borrowed in round 1 (bound above low <=> its \
+           node number above the symbol's node; a target past the total leaves no borrow and raises none, as find()'s \
+           fall-through needs it); the earlier symbol's byte; the next symbol's stream bytes */            \
         u32 sb_;                                                                                           \
-        asm volatile("v_min_u32_dpp %[rm], %[rm], %[rm] " RCX_QP1                                          \
+        asm volatile("v_min3_u32 %[rm], %[x1], %[x2], %[x3]\n\t"                                           \
+                     "v_min3_u32 %[rm], %[rm], %[x4], %[low]\n\t"                                          \
                      "v_addc_co_u32_e64 %[u1], %[c1], 0, %[u1], %[c1]\n\t"                                 \
                      "v_addc_co_u32_e64 %[u2], %[c2], 0, %[u2], %[c2]\n\t"                                 \
-                     "v_min_u32_dpp %[rm], %[rm], %[rm] " RCX_QP2                                          \
+                     "v_min_u32_dpp %[rm], %[rm], %[rm] " RCX_QP1                                          \
                      "v_addc_co_u32_e64 %[u3], %[c3], 0, %[u3], %[c3]\n\t"                                 \
                      "v_addc_co_u32_e64 %[u4], %[c4], 0, %[u4], %[c4]\n\t"                                 \
+                     "v_min_u32_dpp %[rm], %[rm], %[rm] " RCX_QP2                                          \
                      "v_lshl_add_u32 %[sb], %[n], 4, %[t0p3]" /* symbol, if none of the lane's bounds is above */ \
-                     : [u1] "+v"(U1), [u2] "+v"(U2), [u3] "+v"(U3), [u4] "+v"(U4_), [rm] "+v"(rem_),        \
-                       [sb] "=&v"(sb_), [c1] "+s"(c1_), [c2] "+s"(c2_), [c3] "+s"(c3_), [c4] "+s"(c4_)     \
-                     : [n] "v"(node_), [t0p3] "v"(T0p3));                                                  \
+                     RCX_QD_PREV_S_##HP                                                                    \
+                     : [u1] "+v"(U1), [u2] "+v"(U2), [u3] "+v"(U3), [u4] "+v"(U4_), [rm] "=&v"(rem_),       \
+                       [sb] "=&v"(sb_), [c1] "+s"(c1_), [c2] "+s"(c2_), [c3] "+s"(c3_), [c4] "+s"(c4_),    \
+                       [pye] "=&v"(pye_), [pword] "+v"(PWORD)                                              \
+                     : [n] "v"(node_), [t0p3] "v"(T0p3), [low] "v"(in.low), [x1] "v"(x1_), [x2] "v"(x2_),  \
+                       [x3] "v"(x3_), [x4] "v"(x4_), [pc] "s"(p_own_), [psym] "v"(p_sym_), [psh] "n"(PSHIFT)); \
         asm volatile("v_alignbit_b32 %[n4], %[w1], %[w0], %[bp]\n\t" /* the 4 bytes at bp8 ... */           \
                      "v_perm_b32 %[n4], %[n4], %[n4], %[swap]"      /* ... first one on top */              \
                      : [n4] "=&v"(in.n4)                                                                   \
                      : [w0] "v"(in.w0), [w1] "v"(in.w1), [bp] "v"(in.bp8), [swap] "s"(0x00010203u));       \
-        u32 lo_, rg_, sym_, own_, q2_, q3_, q4_, qa_, qb_, qc_, qe_, tot_, pre_, o2_, d2_, ya_, yb_, yc_, ye_, hi_; \
+        u32 lo_, rg_, q2_, q3_, q4_, qa_, qb_, qc_, qe_, tot_, pre_, o2_, d2_, ya_, yb_, yc_, ye_, hi_;    \
         asm volatile("v_add_u32 %[q2], %[lx], %[ly]\n\t"                                                   \
                      "v_add_u32 %[q3], %[q2], %[lz]\n\t"                                                   \
                      "v_add_u32 %[q4], %[q3], %[lw]\n\t"                                                   \
@@ -431,7 +452,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
                      "v_sub_co_u32_e64 %[ya], %[c1], %[d2], %[qa]\n\t"                                     \
                      "v_sub_co_u32_e64 %[yb], %[c2], %[d2], %[qb]\n\t"                                     \
                      "v_sub_co_u32_e64 %[yc], %[c3], %[d2], %[qc]\n\t"                                     \
-                     "v_sub_co_u32_e64 %[ye], %[c4], %[d2], %[qe]\n\t"                                     \
+                     "v_sub_co_u32_e64 %[ye], %[own], %[d2], %[qe]\n\t" /* borrows in the lane that owns the symbol */ \
                      "v_min3_u32 %[lo], %[d2], %[ya], %[yb]\n\t"                                           \
                      "v_max3_u32 %[hi], %[ya], %[yb], %[yc]\n\t"                                           \
                      "v_min_u32 %[lo], %[lo], %[yc]\n\t"                                                   \
@@ -442,25 +463,32 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
                      "v_max_u32_dpp %[hi], %[hi], %[hi] " RCX_QP1                                          \
                      "v_subb_co_u32_e64 %[sym], %[c3], %[sym], 0, %[c3]\n\t"                               \
                      "v_min_u32_dpp %[lo], %[lo], %[lo] " RCX_QP2                                          \
-                     "v_cndmask_b32_e64 %[own], 0, 1, %[c4]\n\t"                                           \
                      "v_max_u32_dpp %[hi], %[hi], %[hi] " RCX_QP2                                          \
-                     "v_cndmask_b32_e64 %[ye], 0, %[sym], %[c4]\n\t"                                       \
-                     "v_sub_u32 %[rg], %[lo], %[hi]\n\t"                                                   \
-                     "v_lshl_or_b32 %[word], %[ye], %[sh], %[word]\n\t"                                    \
-                     "v_and_b32 %[ye], 3, %[sym]\n\t"                                                      \
-                     "v_lshl_add_u32 %[ye], %[ye], 2, %[la]"         /* LDS address of the symbol's count */ \
-                     : [lo] "=&v"(lo_), [rg] "=&v"(rg_), [sym] "=&v"(sym_), [own] "=&v"(own_), [q2] "=&v"(q2_), \
+                     "v_sub_u32 %[rg], %[lo], %[hi]"                                                       \
+                     : [lo] "=&v"(lo_), [rg] "=&v"(rg_), [sym] "=&v"(p_sym_), [own] "=&s"(p_own_), [q2] "=&v"(q2_), \
                        [q3] "=&v"(q3_), [q4] "=&v"(q4_), [qa] "=&v"(qa_), [qb] "=&v"(qb_), [qc] "=&v"(qc_),  \
                        [qe] "=&v"(qe_), [tot] "=&v"(tot_), [pre] "=&v"(pre_), [o2] "=&v"(o2_), [d2] "=&v"(d2_), \
                        [ya] "=&v"(ya_), [yb] "=&v"(yb_), [yc] "=&v"(yc_), [ye] "=&v"(ye_), [hi] "=&v"(hi_),  \
-                       [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_), [c4] "=&s"(c4_), [word] "+v"(WORD)  \
+                       [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_)                                   \
                      : [lx] "v"(l_.x), [ly] "v"(l_.y), [lz] "v"(l_.z), [lw] "v"(l_.w), [t] "v"(t_),        \
-                       [rem] "v"(rem_), [m1] "v"(m1), [m2] "v"(m2), [sb] "v"(sb_), [sh] "n"(SHIFT),        \
-                       [la] "v"(la_));                                                                     \
+                       [rem] "v"(rem_), [m1] "v"(m1), [m2] "v"(m2), [sb] "v"(sb_));                        \
         RCX_QUAD_STAMP(1);                                                                                 \
         in.low = lo_;   /* :906 */                                                                         \
         in.range = rg_; /* :907 */                                                                         \
-        (void)__hip_atomic_fetch_add(reinterpret_cast<RcxLdsU32*>(ye_), own_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); /* :916 */ \
+        p_la_ = la_;                                                                                       \
+    }
+// The byte and the count of the last symbol decoded (no symbol follows that would make them): into WORD at bit SHIFT.
+#define RCX_QUAD_DEC_FINISH(WORD, SHIFT)                                                                    \
+    {                                                                                                      \
+        u32 pown_, pad_, pye_;                                                                             \
+        asm volatile("v_cndmask_b32_e64 %[pown], 0, 1, %[pc]\n\t"                                          \
+                     "v_and_b32 %[pad], 3, %[psym]\n\t"                                                    \
+                     "v_cndmask_b32_e64 %[pye], 0, %[psym], %[pc]\n\t"                                     \
+                     "v_lshl_add_u32 %[pad], %[pad], 2, %[pla]\n\t"                                        \
+                     "v_lshl_or_b32 %[pword], %[pye], %[psh], %[pword]"                                    \
+                     : [pown] "=&v"(pown_), [pad] "=&v"(pad_), [pye] "=&v"(pye_), [pword] "+v"(WORD)        \
+                     : [pc] "s"(p_own_), [psym] "v"(p_sym_), [pla] "v"(p_la_), [psh] "n"(SHIFT));          \
+        (void)__hip_atomic_fetch_add(reinterpret_cast<RcxLdsU32*>(pad_), pown_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); /* :916 */ \
     }
 
     // The divisors of the next 16 symbols are converted and written to LDS at every top-up, and the 16 after
@@ -503,26 +531,28 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
             DivQ k_next = stage[0];
 #if defined(RCX_STAMP_DEC)
             unsigned long long stamp_t_[4] = {0, 0, 0, 0};
-#define RCX_QUAD_STEP(S, W)                                      \
+#define RCX_QUAD_STEP(S, HP, PW)                                 \
     {                                                            \
         const DivQ kk = k_next;                                  \
         if ((S) + 1 < 16) k_next = stage[(S) + 1];               \
         const bool stamp_now_ = (S) == 8 || (S) == 9;            \
         const int stamp_at_ = (S) == 8 ? 0 : 2;                  \
-        RCX_QUAD_DEC_SYMBOL(kk, W, 8 * ((S) & 3));               \
+        RCX_QUAD_DEC_SYMBOL(kk, HP, PW, (8 * (((S) + 3) & 3))); \
     }
 #else
-#define RCX_QUAD_STEP(S, W)                                      \
+#define RCX_QUAD_STEP(S, HP, PW)                                 \
     {                                                            \
         const DivQ kk = k_next;                                  \
         if ((S) + 1 < 16) k_next = stage[(S) + 1];               \
-        RCX_QUAD_DEC_SYMBOL(kk, W, 8 * ((S) & 3));               \
+        RCX_QUAD_DEC_SYMBOL(kk, HP, PW, (8 * (((S) + 3) & 3))); \
     }
 #endif
-            RCX_QUAD_STEP(0, w0_) RCX_QUAD_STEP(1, w0_) RCX_QUAD_STEP(2, w0_) RCX_QUAD_STEP(3, w0_)
-            RCX_QUAD_STEP(4, w1_) RCX_QUAD_STEP(5, w1_) RCX_QUAD_STEP(6, w1_) RCX_QUAD_STEP(7, w1_)
-            RCX_QUAD_STEP(8, w2_) RCX_QUAD_STEP(9, w2_) RCX_QUAD_STEP(10, w2_) RCX_QUAD_STEP(11, w2_)
-            RCX_QUAD_STEP(12, w3_) RCX_QUAD_STEP(13, w3_) RCX_QUAD_STEP(14, w3_) RCX_QUAD_STEP(15, w3_)
+            // (a step makes the byte of the step before it: RCX_QUAD_DEC_SYMBOL)
+            RCX_QUAD_STEP(0, 0, w0_) RCX_QUAD_STEP(1, 1, w0_) RCX_QUAD_STEP(2, 1, w0_) RCX_QUAD_STEP(3, 1, w0_)
+            RCX_QUAD_STEP(4, 1, w0_) RCX_QUAD_STEP(5, 1, w1_) RCX_QUAD_STEP(6, 1, w1_) RCX_QUAD_STEP(7, 1, w1_)
+            RCX_QUAD_STEP(8, 1, w1_) RCX_QUAD_STEP(9, 1, w2_) RCX_QUAD_STEP(10, 1, w2_) RCX_QUAD_STEP(11, 1, w2_)
+            RCX_QUAD_STEP(12, 1, w2_) RCX_QUAD_STEP(13, 1, w3_) RCX_QUAD_STEP(14, 1, w3_) RCX_QUAD_STEP(15, 1, w3_)
+            RCX_QUAD_DEC_FINISH(w3_, 24)
 #undef RCX_QUAD_STEP
 #if defined(RCX_STAMP_DEC)
             stamp_sum_[0] += stamp_t_[1] - stamp_t_[0]; // symbol 8: leaf read issued -> round 2 done
@@ -566,13 +596,19 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
                 const int stamp_at_ = 0;
                 unsigned long long stamp_t_[4];
 #endif
-                RCX_QUAD_DEC_SYMBOL(k, part, 0);
+                RCX_QUAD_DEC_SYMBOL(k, 0, part, 0);
+                RCX_QUAD_DEC_FINISH(part, 0);
                 part = rcx_quad_or(part);
                 if (leader) out[i] = (u8)part;
             }
         }
     }
 #undef RCX_QUAD_DEC_SYMBOL
+#undef RCX_QUAD_DEC_FINISH
+#undef RCX_QD_PREV_A_0
+#undef RCX_QD_PREV_A_1
+#undef RCX_QD_PREV_S_0
+#undef RCX_QD_PREV_S_1
 #undef RCX_QUAD_STAGE_PUT
 #undef RCX_QUAD_STAGE_GET
 #undef RCX_QP1
