@@ -432,20 +432,15 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
                        [pye] "=&v"(pye_), [pword] "+v"(PWORD)                                              \
                      : [n] "v"(node_), [t0p3] "v"(T0p3), [low] "v"(in.low), [x1] "v"(x1_), [x2] "v"(x2_),  \
                        [x3] "v"(x3_), [x4] "v"(x4_), [pc] "s"(p_own_), [psym] "v"(p_sym_), [psh] "n"(PSHIFT)); \
-        asm volatile("v_alignbit_b32 %[n4], %[w1], %[w0], %[bp]\n\t" /* the 4 bytes at bp8 ... */           \
-                     "v_perm_b32 %[n4], %[n4], %[n4], %[swap]"      /* ... first one on top */              \
-                     : [n4] "=&v"(in.n4)                                                                   \
-                     : [w0] "v"(in.w0), [w1] "v"(in.w1), [bp] "v"(in.bp8), [swap] "s"(0x00010203u));       \
-        u32 lo_, rg_, q2_, q3_, q4_, qa_, qb_, qc_, qe_, tot_, pre_, o2_, d2_, ya_, yb_, yc_, ye_, hi_;    \
-        asm volatile("v_add_u32 %[q2], %[lx], %[ly]\n\t"                                                   \
-                     "v_add_u32 %[q3], %[q2], %[lz]\n\t"                                                   \
-                     "v_add_u32 %[q4], %[q3], %[lw]\n\t"                                                   \
-                     "v_mul_u32_u24 %[qe], %[q4], %[t]\n\t"                                                \
-                     "v_mul_u32_u24 %[qa], %[lx], %[t]\n\t"                                                \
-                     "v_mul_u32_u24 %[qb], %[q2], %[t]\n\t"                                                \
+        u32 lo_, rg_, qa_, qb_, qc_, qe_, tot_, pre_, o2_, d2_, ya_, yb_, yc_, ye_, hi_;                   \
+        asm volatile("v_mul_u32_u24 %[qa], %[lx], %[t]\n\t"      /* the lane's four inclusive sums, scaled: every */ \
+                     "v_mad_u32_u24 %[qb], %[ly], %[t], %[qa]\n\t" /* sum is below total x t <= range < 2^32 */      \
+                     "v_mad_u32_u24 %[qc], %[lz], %[t], %[qb]\n\t"                                         \
+                     "v_mad_u32_u24 %[qe], %[lw], %[t], %[qc]\n\t"                                         \
+                     "v_alignbit_b32 %[n4], %[w1], %[w0], %[bp]\n\t" /* (the next symbol's 4 stream bytes at bp8 ... */ \
+                     "v_perm_b32 %[n4], %[n4], %[n4], %[swap]\n\t" /* ... first one on top: here they separate qe from its use across the quad) */ \
                      "v_add_u32_dpp %[tot], %[qe], %[qe] " RCX_QP1 /* the lanes' sums are scanned scaled: (a+b)t = at+bt */ \
                      "v_and_b32_dpp %[pre], %[qe], %[m1] " RCX_QP1                                         \
-                     "v_mul_u32_u24 %[qc], %[q3], %[t]\n\t"                                                \
                      "v_sub_u32 %[d2], %[rem], %[pre]\n\t"                                                 \
                      "v_and_b32_dpp %[o2], %[tot], %[m2] " RCX_QP2                                         \
                      "v_sub_u32 %[d2], %[d2], %[o2]\n\t"     /* rem - t x the counts of the node's symbols in lower lanes */ \
@@ -465,13 +460,14 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
                      "v_min_u32_dpp %[lo], %[lo], %[lo] " RCX_QP2                                          \
                      "v_max_u32_dpp %[hi], %[hi], %[hi] " RCX_QP2                                          \
                      "v_sub_u32 %[rg], %[lo], %[hi]"                                                       \
-                     : [lo] "=&v"(lo_), [rg] "=&v"(rg_), [sym] "=&v"(p_sym_), [own] "=&s"(p_own_), [q2] "=&v"(q2_), \
-                       [q3] "=&v"(q3_), [q4] "=&v"(q4_), [qa] "=&v"(qa_), [qb] "=&v"(qb_), [qc] "=&v"(qc_),  \
+                     : [lo] "=&v"(lo_), [rg] "=&v"(rg_), [sym] "=&v"(p_sym_), [own] "=&s"(p_own_), [n4] "=&v"(in.n4), \
+                       [qa] "=&v"(qa_), [qb] "=&v"(qb_), [qc] "=&v"(qc_),                                   \
                        [qe] "=&v"(qe_), [tot] "=&v"(tot_), [pre] "=&v"(pre_), [o2] "=&v"(o2_), [d2] "=&v"(d2_), \
                        [ya] "=&v"(ya_), [yb] "=&v"(yb_), [yc] "=&v"(yc_), [ye] "=&v"(ye_), [hi] "=&v"(hi_),  \
                        [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_)                                   \
                      : [lx] "v"(l_.x), [ly] "v"(l_.y), [lz] "v"(l_.z), [lw] "v"(l_.w), [t] "v"(t_),        \
-                       [rem] "v"(rem_), [m1] "v"(m1), [m2] "v"(m2), [sb] "v"(sb_));                        \
+                       [rem] "v"(rem_), [m1] "v"(m1), [m2] "v"(m2), [sb] "v"(sb_),                         \
+                       [w0] "v"(in.w0), [w1] "v"(in.w1), [bp] "v"(in.bp8), [swap] "s"(0x00010203u));       \
         RCX_QUAD_STAMP(1);                                                                                 \
         in.low = lo_;   /* :906 */                                                                         \
         in.range = rg_; /* :907 */                                                                         \

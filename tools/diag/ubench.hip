@@ -29,7 +29,7 @@
                      : [t0] "=&s"(t0), [t1] "=&s"(t1), [a] "+v"(v0), [b] "+v"(v1), [c] "+v"(v2), [d] "+v"(v3) \
                      :                                                                            \
                      : "vcc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "v40", "v41", "v42", \
-                       "v43", "v44", "v45", "v46", "v47", "memory");                             \
+                       "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "memory");                             \
         if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;                                \
         sink[threadIdx.x] = v0 + v1 + v2 + v3 + lds[threadIdx.x];                                 \
     }
@@ -72,6 +72,27 @@ BENCH_KERNEL(k_readlane, "", "v_readfirstlane_b32 s20, %[a]\n\tv_add_u32 %[a], s
 BENCH_KERNEL(k_salu, "", "s_add_u32 s20, s20, 1")
 BENCH_KERNEL(k_valu_salu, "", "v_add_u32 %[a], %[a], %[b]\n\ts_add_u32 s20, s20, 1")
 
+
+// LDS instructions inside a stream of vector instructions, results never waited for: what does ISSUING one cost a lone
+// wave?  Eight dependent adds (k_t_none: 8 x 4.17) and one LDS operation per copy; the difference is the LDS operation.
+#define V8 "v_add_u32 %[a], %[a], %[b]\n\tv_add_u32 %[a], %[a], %[b]\n\tv_add_u32 %[a], %[a], %[b]\n\tv_add_u32 %[a], %[a], %[b]\n\t" \
+           "v_add_u32 %[a], %[a], %[b]\n\tv_add_u32 %[a], %[a], %[b]\n\tv_add_u32 %[a], %[a], %[b]\n\tv_add_u32 %[a], %[a], %[b]\n\t"
+#define TSET "v_lshlrev_b32 v40, 4, %[c]\n\tv_and_b32 v40, 0x3ff0, v40\n\tv_mov_b32 v41, 1\n\tv_mov_b32 v42, 1\n\tv_mov_b32 v43, 1\n\tv_mov_b32 v44, 1\n\tv_mov_b32 v45, 1\n\tv_mov_b32 v46, 1\n\tv_mov_b32 v47, 1"
+BENCH_KERNEL(k_t_none, TSET, V8)
+BENCH_KERNEL(k_t_rd_b32, TSET, V8 "ds_read_b32 v48, v40")
+BENCH_KERNEL(k_t_rd_b64, TSET, V8 "ds_read_b64 v[48:49], v40")
+BENCH_KERNEL(k_t_rd_b128, TSET, V8 "ds_read_b128 v[48:51], v40")
+BENCH_KERNEL(k_t_rd2_b32, TSET, V8 "ds_read2_b32 v[48:49], v40 offset1:1")
+BENCH_KERNEL(k_t_rd2_b64, TSET, V8 "ds_read2_b64 v[48:51], v40 offset1:1")
+BENCH_KERNEL(k_t_wr_b32, TSET, V8 "ds_write_b32 v40, v41")
+BENCH_KERNEL(k_t_wr_b8, TSET, V8 "ds_write_b8 v40, v41")
+BENCH_KERNEL(k_t_wr_b64, TSET, V8 "ds_write_b64 v40, v[42:43]")
+BENCH_KERNEL(k_t_wr_b128, TSET, V8 "ds_write_b128 v40, v[44:47]")
+BENCH_KERNEL(k_t_add, TSET, V8 "ds_add_u32 v40, v41")
+BENCH_KERNEL(k_t_add_rd128, TSET, V8 "ds_add_u32 v40, v41\n\tds_read_b128 v[48:51], v40")
+BENCH_KERNEL(k_t_wr128_rd128, TSET, V8 "ds_write_b128 v40, v[44:47]\n\tds_read_b128 v[48:51], v40")
+BENCH_KERNEL(k_t_waitcnt, TSET, V8 "s_waitcnt lgkmcnt(0)")
+BENCH_KERNEL(k_t_sdwa, TSET, V8 "v_cndmask_b32_sdwa %[d], %[d], %[b], vcc dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_0")
 
 // ---------------------------------------------------------------------------------------------
 // The quad decoder's LDS pattern: per "symbol" one broadcast ds_read2_b64, PRE dependent VALU ops, a
@@ -279,6 +300,8 @@ int main(int argc, char** argv)
                                C(k_lds_b64, 1), C(k_lds_b128, 2), C(k_lds_b128_same, 2), C(k_lds_read2, 2), C(k_lds_add, 1), C(k_lds_add_read, 3),
                                C(k_branch_taken, 2), C(k_branch_not, 2), C(k_cbranch_taken, 2), C(k_cvt_rcp, 2), C(k_ffbh, 1),
                                C(k_readlane, 2), C(k_salu, 1), C(k_valu_salu, 2),
+                               C(k_t_none, 8), C(k_t_rd_b32, 9), C(k_t_rd_b64, 9), C(k_t_rd_b128, 9), C(k_t_rd2_b32, 9), C(k_t_rd2_b64, 9), C(k_t_wr_b32, 9), C(k_t_wr_b8, 9),
+                               C(k_t_wr_b64, 9), C(k_t_wr_b128, 9), C(k_t_add, 9), C(k_t_add_rd128, 10), C(k_t_wr128_rd128, 10), C(k_t_waitcnt, 9), C(k_t_sdwa, 9),
                                C(k_sym_gap0, 65), C(k_sym_gap4, 69), C(k_sym_gap8, 73), C(k_sym_gap12, 77), C(k_sym_gap16, 81), C(k_sym_gap24, 89),
                                C(k_sym_gap32, 97), C(k_sym_gap12_noatom, 76), C(k_sym_gap12_b64, 77), C(k_sym_gap0_b64, 65),
                                C(k_blk_a, 17), C(k_blk_u, 9), C(k_blk_c, 36), C(k_blk_auc, 62), C(k_loop_auc, 62), C(k_loop_add62, 62), C(k_loop_min3_62, 62),
