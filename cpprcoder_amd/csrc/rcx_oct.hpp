@@ -761,6 +761,7 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
                 const RcxLdsDivQ* st = reinterpret_cast<const RcxLdsDivQ*>(st_lds);
                 U4 eq[RCX_MC_CHUNK];
                 RcxDivQv kq[RCX_MC_CHUNK];
+                u32 rec_even = 0;
 #define RCX_A_ISSUE(T)                                                                                              \
     {                                                                                                               \
         eq[T].x = rs[RCX_RING_AT((T), 0)], eq[T].y = rs[RCX_RING_AT((T), 1)], eq[T].z = rs[RCX_RING_AT((T), 2)];    \
@@ -776,7 +777,13 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
                     const RcxDivQv kk = kq[s];
                     u32 rec = 0; // past the end of a short block: a record that does nothing
                     if (FULL || i0 + s < len) rec = enc.arith_q(e.x + e.y + e.z, e.w, kk.x, kk.y, ((u64)kk.w << 32) | kk.z);
-                    ws2[s * RCX_LANES] = rec;
+                    // two symbols' records leave as one ds_write2st64_b32 (consecutive symbols are 64 dwords apart): an LDS
+                    // instruction costs a lone wave 12-16 cycles of issue whatever it carries (tools/diag/ubench.hip k_t_*)
+                    if ((s & 1u) == 0) rec_even = rec;
+                    else {
+                        ws2[(s - 1) * RCX_LANES] = rec_even;
+                        ws2[s * RCX_LANES] = rec;
+                    }
                 }
 #undef RCX_A_ISSUE
             }
@@ -784,13 +791,14 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
             // ---- writer: chunk k-2 from ring2[(k-2)&1] ----
             if (k >= 2) {
                 const u32* rs2 = ring2 + ((k - 2) & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
-                u32 r_next = rs2[0];
+                u32 ra_next = rs2[0], rb_next = rs2[RCX_LANES]; // (pairs: one ds_read2st64_b32)
                 wr.safe_from = wr.pos > RCX_OUT_MARGIN ? wr.pos - RCX_OUT_MARGIN : 0u;
 #pragma unroll
-                for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
-                    const u32 rec = r_next;
-                    if (s + 1 < RCX_MC_CHUNK) r_next = rs2[(s + 1) * RCX_LANES];
-                    wr.emit(rec);
+                for (u32 s = 0; s < RCX_MC_CHUNK; s += 2) {
+                    const u32 ra = ra_next, rb = rb_next;
+                    if (s + 2 < RCX_MC_CHUNK) ra_next = rs2[(s + 2) * RCX_LANES], rb_next = rs2[(s + 3) * RCX_LANES];
+                    wr.emit(ra);
+                    wr.emit(rb);
                 }
                 out_pos[lane] = wr.pos; // for the drain of the next iteration
             }
@@ -839,6 +847,7 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
             // and more with five waves on the LDS unit, i.e. more than one symbol of a light wave -- hides behind the
             // arithmetic of the symbols in between (the updates need only the symbol, not the read data).
             U4 ga[RCX_MC_CHUNK], gb[RCX_MC_CHUNK]; // (indices are compile-time constants: registers)
+            u32 held = 0;
             if (wave == 2) {
 #define RCX_M2_ISSUE(T)                                                       \
     {                                                                         \
@@ -872,7 +881,11 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
                 for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
                     if (s + RCX_MODEL_AHEAD < RCX_MC_CHUNK) RCX_M1_ISSUE(s + RCX_MODEL_AHEAD);
                     const u32 cc = rcx_byte_of(piece, s);
-                    if (FULL || i0 + s < len) ws[RCX_RING_AT(s, 1)] = rcx_pre4(ga[s], (cc >> 2) & 3);
+                    const u32 sum1 = rcx_pre4(ga[s], (cc >> 2) & 3);
+                    if (FULL) { // (pairs: one ds_write2st64_b32)
+                        if ((s & 1u) == 0) held = sum1;
+                        else ws[RCX_RING_AT(s - 1, 1)] = held, ws[RCX_RING_AT(s, 1)] = sum1;
+                    } else if (i0 + s < len) ws[RCX_RING_AT(s, 1)] = sum1;
                 }
 #undef RCX_M1_ISSUE
             } else {
