@@ -635,6 +635,9 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
 // and such a block is marked in `redo` and encoded again by rcx_enc_adaptive_k.
 // ===========================================================================
 #define RCX_MC5_THREADS 320
+#if !defined(RCX_DRAIN_WAVE)
+#define RCX_DRAIN_WAVE 4 /* which model wave drains the output rings: 4 (level 1, shares a SIMD with the arithmetic wave) or 3 (leaf level) */
+#endif
 // The ring between the model waves and the arithmetic wave: four dwords per symbol and lane.  Kept as 16 contiguous
 // bytes per lane (one ds_read_b128 for the arithmetic wave; the model waves' 4-byte stores hit each bank four times)
 // or, RCX_RING_PLANAR=1, as four dword planes (conflict-free stores, two ds_read2st64_b32).
@@ -803,32 +806,61 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
                 out_pos[lane] = wr.pos; // for the drain of the next iteration
             }
         } else {
-          if (wave == 4) {
-            // ---- drain: whole 16-byte pieces below (the writer's position one barrier ago - margin) ----
-            const u32 p = out_pos[lane];
-            const u32 limit = p > RCX_OUT_MARGIN ? (p - RCX_OUT_MARGIN) & ~15u : 0u;
-            while (__any(live && drained + 16 <= limit && drained + 16 <= cap)) {
-                const bool go = live && drained + 16 <= limit && drained + 16 <= cap;
-                if (go) {
-                    const u32* w = wr.ring_lane;
-                    const u32 w0 = drained >> 2;
-                    RcxU4Unaligned piece;
-                    piece.x = w[((w0 + 0) % RCX_OUT_RING_WORDS) * RCX_LANES];
-                    piece.y = w[((w0 + 1) % RCX_OUT_RING_WORDS) * RCX_LANES];
-                    piece.z = w[((w0 + 2) % RCX_OUT_RING_WORDS) * RCX_LANES];
-                    piece.w = w[((w0 + 3) % RCX_OUT_RING_WORDS) * RCX_LANES];
-                    *reinterpret_cast<RcxU4Unaligned*>(payload + drained) = piece;
-                    drained += 16;
+          // ---- drain: whole 16-byte pieces below (the writer's position one barrier ago - margin) ----
+          // Asked for here, stored behind the chunk's model work: the writer's position and -- before it is known whether they
+          // may leave -- the next four words of the block's ring.  (Read and stored in one go, the five LDS reads' latency
+          // was this wave's, which shares its SIMD with the arithmetic wave: 28 cycles a symbol.)
+          u32 drain_p = 0;
+          RcxU4Unaligned drain_piece;
+          drain_piece.x = drain_piece.y = drain_piece.z = drain_piece.w = 0;
+          if (wave == RCX_DRAIN_WAVE) {
+            drain_p = out_pos[lane];
+            const u32* w = wr.ring_lane + ((drained >> 2) % RCX_OUT_RING_WORDS) * RCX_LANES; // (drained is a multiple of 16: no wrap inside the piece)
+            drain_piece.x = w[0];
+            drain_piece.y = w[RCX_LANES];
+            drain_piece.z = w[2 * RCX_LANES];
+            drain_piece.w = w[3 * RCX_LANES];
+          }
+          // (up to three pieces a chunk: 16 symbols make at most 48 bytes.  No loop: in front of a loop the compiler waits for
+          // every store in flight, and a store's round trip is a quarter of a chunk's time.)
+          auto drain_store = [&]() {
+            const u32 limit = drain_p > RCX_OUT_MARGIN ? (drain_p - RCX_OUT_MARGIN) & ~15u : 0u;
+            if (live && drained + 16 <= limit && drained + 16 <= cap) {
+                *reinterpret_cast<RcxU4Unaligned*>(payload + drained) = drain_piece;
+                drained += 16;
+            }
+#pragma unroll
+            for (u32 more = 0; more < 2; ++more) {
+                if (__any(live && drained + 16 <= limit && drained + 16 <= cap)) { // a block that is more than one piece behind
+                    if (live && drained + 16 <= limit && drained + 16 <= cap) {
+                        const u32* w = wr.ring_lane + ((drained >> 2) % RCX_OUT_RING_WORDS) * RCX_LANES;
+                        RcxU4Unaligned piece;
+                        piece.x = w[0];
+                        piece.y = w[RCX_LANES];
+                        piece.z = w[2 * RCX_LANES];
+                        piece.w = w[3 * RCX_LANES];
+                        *reinterpret_cast<RcxU4Unaligned*>(payload + drained) = piece;
+                        drained += 16;
+                    }
                 }
             }
-          }
+          };
+          if (k >= nchunks && wave == RCX_DRAIN_WAVE) drain_store();
           if (k < nchunks) {
             // ---- model: chunk k ----
             const u32 i0 = k * RCX_MC_CHUNK;
             u32* ws = ring + (k & 1u) * (4 * RCX_MC_CHUNK * RCX_LANES) + RCX_RING_LANE * lane;
             U4 piece;
+            if (FULL) piece = piece_ahead;
+            if (wave == RCX_DRAIN_WAVE) {
+                // The stores go out between the wait for this chunk's input (asked for a chunk ago: it is there) and the
+                // request for the next chunk's: memory operations complete in order as far as s_waitcnt vmcnt can tell, so
+                // a wait for input behind a store just issued would wait for that store (that was 28 cycles a symbol on
+                // the SIMD this wave shares with the arithmetic wave).
+                if (FULL) asm volatile("" ::"v"(piece.x), "v"(piece.y), "v"(piece.z), "v"(piece.w));
+                drain_store();
+            }
             if (FULL) {
-                piece = piece_ahead;
                 if (k + 1 < nchunks) piece_ahead = *reinterpret_cast<const U4*>(in + i0 + RCX_MC_CHUNK);
             } else if (i0 + RCX_MC_CHUNK <= len && (reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
                 piece = *reinterpret_cast<const U4*>(in + i0); // a whole, aligned chunk of a ragged block (or of a single stream)
@@ -847,7 +879,7 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
             // and more with five waves on the LDS unit, i.e. more than one symbol of a light wave -- hides behind the
             // arithmetic of the symbols in between (the updates need only the symbol, not the read data).
             U4 ga[RCX_MC_CHUNK], gb[RCX_MC_CHUNK]; // (indices are compile-time constants: registers)
-            u32 held = 0;
+            u32 held = 0, held_f = 0;
             if (wave == 2) {
 #define RCX_M2_ISSUE(T)                                                       \
     {                                                                         \
@@ -865,7 +897,11 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
                 for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
                     if (s + RCX_MODEL_AHEAD < RCX_MC_CHUNK) RCX_M2_ISSUE(s + RCX_MODEL_AHEAD);
                     const u32 cc = rcx_byte_of(piece, s);
-                    if (FULL || i0 + s < len) ws[RCX_RING_AT(s, 0)] = rcx_pre4(ga[s], cc >> 6) + rcx_pre4(gb[s], (cc >> 4) & 3);
+                    const u32 sum32 = rcx_pre4(ga[s], cc >> 6) + rcx_pre4(gb[s], (cc >> 4) & 3);
+                    if (FULL) { // (pairs: one ds_write2st64_b32)
+                        if ((s & 1u) == 0) held = sum32;
+                        else ws[RCX_RING_AT(s - 1, 0)] = held, ws[RCX_RING_AT(s, 0)] = sum32;
+                    } else if (i0 + s < len) ws[RCX_RING_AT(s, 0)] = sum32;
                 }
 #undef RCX_M2_ISSUE
             } else if (wave == 4) {
@@ -901,9 +937,16 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
                 for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
                     if (s + RCX_MODEL_AHEAD < RCX_MC_CHUNK) RCX_M0_ISSUE(s + RCX_MODEL_AHEAD);
                     const u32 cc = rcx_byte_of(piece, s);
-                    if (FULL || i0 + s < len) {
-                        ws[RCX_RING_AT(s, 2)] = rcx_pre4(ga[s], cc & 3);
-                        ws[RCX_RING_AT(s, 3)] = rcx_sel4(ga[s], cc & 3);
+                    const u32 sum0 = rcx_pre4(ga[s], cc & 3), f0 = rcx_sel4(ga[s], cc & 3);
+                    if (FULL) { // (pairs: two ds_write2st64_b32 for two symbols)
+                        if ((s & 1u) == 0) held = sum0, held_f = f0;
+                        else {
+                            ws[RCX_RING_AT(s - 1, 2)] = held, ws[RCX_RING_AT(s, 2)] = sum0;
+                            ws[RCX_RING_AT(s - 1, 3)] = held_f, ws[RCX_RING_AT(s, 3)] = f0;
+                        }
+                    } else if (i0 + s < len) {
+                        ws[RCX_RING_AT(s, 2)] = sum0;
+                        ws[RCX_RING_AT(s, 3)] = f0;
                     }
                 }
 #undef RCX_M0_ISSUE
@@ -991,7 +1034,7 @@ __global__ __launch_bounds__(RCX_MC5_THREADS) void rcx_enc_mc5_k(const u8* __res
     else rcx_mc5_pipeline<false>(wave, lane, len, nchunks, in, divtab, tree, stage, ring, ring2, enc, ahead, wr, out_pos, drained, payload, cap, live);
 
     if (wave == 0) final_low[lane] = enc.low;
-    if (wave == 4) {
+    if (wave == RCX_DRAIN_WAVE) {
         out_drained[lane] = drained;
         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the drained pieces are in memory before wave 1 may read them
     }
