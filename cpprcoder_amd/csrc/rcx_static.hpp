@@ -230,49 +230,70 @@ __device__ __forceinline__ void rcx_static3_pipeline(u32 wave, u32 lane, u32 len
                 const U4* rs = ring + ((k - 1) & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
                 u32* ws2 = ring2 + ((k - 1) & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
                 U4 e_next = rs[0];
+                u32 rec_even = 0;
 #pragma unroll
                 for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
                     const U4 e = e_next;
                     if (s + 1 < RCX_MC_CHUNK) e_next = rs[(s + 1) * RCX_LANES];
                     u32 rec = 0;
                     if (FULL || i0 + s < len) rec = enc.template arith<WIDE>(e.x, e.w, kdiv); // cpprcoder.h:402-408
-                    ws2[s * RCX_LANES] = rec;
+                    if ((s & 1u) == 0) rec_even = rec; // (two symbols' records per LDS instruction: see rcx_mc5_pipeline)
+                    else {
+                        ws2[(s - 1) * RCX_LANES] = rec_even;
+                        ws2[s * RCX_LANES] = rec;
+                    }
                 }
             }
         } else if (wave == 1) {
             // ---- writer: chunk k-2 ----
             if (k >= 2) {
                 const u32* rs2 = ring2 + ((k - 2) & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
-                u32 r_next = rs2[0];
+                u32 ra_next = rs2[0], rb_next = rs2[RCX_LANES];
                 wr.safe_from = wr.pos > RCX_OUT_MARGIN ? wr.pos - RCX_OUT_MARGIN : 0u;
 #pragma unroll
-                for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
-                    const u32 rec = r_next;
-                    if (s + 1 < RCX_MC_CHUNK) r_next = rs2[(s + 1) * RCX_LANES];
-                    wr.emit(rec);
+                for (u32 s = 0; s < RCX_MC_CHUNK; s += 2) {
+                    const u32 ra = ra_next, rb = rb_next;
+                    if (s + 2 < RCX_MC_CHUNK) ra_next = rs2[(s + 2) * RCX_LANES], rb_next = rs2[(s + 3) * RCX_LANES];
+                    wr.emit(ra);
+                    wr.emit(rb);
                 }
                 out_pos[lane] = wr.pos;
             }
         } else {
-            // ---- drain (see rcx_mc5_pipeline) ----
+            // ---- drain (see rcx_mc5_pipeline: the reads here, the stores between the wait for this chunk's input and the
+            // request for the next chunk's, no loop) ----
+            const u32 drain_p = out_pos[lane];
+            RcxU4Unaligned drain_piece;
             {
-                const u32 p = out_pos[lane];
-                const u32 limit = p > RCX_OUT_MARGIN ? (p - RCX_OUT_MARGIN) & ~15u : 0u;
-                while (__any(live && drained + 16 <= limit && drained + 16 <= cap)) {
-                    const bool go = live && drained + 16 <= limit && drained + 16 <= cap;
-                    if (go) {
-                        const u32* w = wr.ring_lane;
-                        const u32 w0 = drained >> 2;
-                        RcxU4Unaligned piece;
-                        piece.x = w[((w0 + 0) % RCX_OUT_RING_WORDS) * RCX_LANES];
-                        piece.y = w[((w0 + 1) % RCX_OUT_RING_WORDS) * RCX_LANES];
-                        piece.z = w[((w0 + 2) % RCX_OUT_RING_WORDS) * RCX_LANES];
-                        piece.w = w[((w0 + 3) % RCX_OUT_RING_WORDS) * RCX_LANES];
-                        *reinterpret_cast<RcxU4Unaligned*>(payload + drained) = piece;
-                        drained += 16;
+                const u32* w = wr.ring_lane + ((drained >> 2) % RCX_OUT_RING_WORDS) * RCX_LANES; // (drained is a multiple of 16)
+                drain_piece.x = w[0];
+                drain_piece.y = w[RCX_LANES];
+                drain_piece.z = w[2 * RCX_LANES];
+                drain_piece.w = w[3 * RCX_LANES];
+            }
+            auto drain_store = [&]() {
+                const u32 limit = drain_p > RCX_OUT_MARGIN ? (drain_p - RCX_OUT_MARGIN) & ~15u : 0u;
+                if (live && drained + 16 <= limit && drained + 16 <= cap) {
+                    *reinterpret_cast<RcxU4Unaligned*>(payload + drained) = drain_piece;
+                    drained += 16;
+                }
+#pragma unroll
+                for (u32 more = 0; more < 2; ++more) {
+                    if (__any(live && drained + 16 <= limit && drained + 16 <= cap)) {
+                        if (live && drained + 16 <= limit && drained + 16 <= cap) {
+                            const u32* w = wr.ring_lane + ((drained >> 2) % RCX_OUT_RING_WORDS) * RCX_LANES;
+                            RcxU4Unaligned piece;
+                            piece.x = w[0];
+                            piece.y = w[RCX_LANES];
+                            piece.z = w[2 * RCX_LANES];
+                            piece.w = w[3 * RCX_LANES];
+                            *reinterpret_cast<RcxU4Unaligned*>(payload + drained) = piece;
+                            drained += 16;
+                        }
                     }
                 }
-            }
+            };
+            if (k >= nchunks) drain_store();
             // ---- lookups: chunk k ----
             if (k < nchunks) {
                 const u32 i0 = k * RCX_MC_CHUNK;
@@ -280,6 +301,10 @@ __device__ __forceinline__ void rcx_static3_pipeline(u32 wave, u32 lane, u32 len
                 U4 piece;
                 if (FULL) {
                     piece = piece_ahead;
+                    asm volatile("" ::"v"(piece.x), "v"(piece.y), "v"(piece.z), "v"(piece.w)); // (the input has arrived before a store is issued)
+                }
+                drain_store();
+                if (FULL) {
                     if (k + 1 < nchunks) piece_ahead = *reinterpret_cast<const U4*>(in + i0 + RCX_MC_CHUNK);
                 } else {
                     u32 w[4] = {0, 0, 0, 0};
@@ -686,6 +711,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_static_quad_k(const u8* __
     u8* out = dst + at;
     const bool leader = live && in_use && j == 0;
     const u32 leaves_lds = (u32)reinterpret_cast<uintptr_t>(leaves);
+    const u32 ring_lds = (u32)reinterpret_cast<uintptr_t>(block_ring);
     u32 worst_node = 0;            // 16 = a target past the table
     u32 least_range = 0xFFFFFFFFu; // 0 = a symbol of count 0
 
@@ -702,36 +728,49 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_static_quad_k(const u8* __
         const u32 a1_ = U1 * t_, a2_ = U2 * t_, a3_ = U3 * t_, a4_ = U4_ * t_;                             \
         u32 node_, rem_, ro_, la_, x1_, x2_, x3_, x4_;                                                     \
         u64 c1_, c2_, c3_, c4_;                                                                            \
+        /* (ordered as in rcx_dec_quad_k: the node index first -- the leaf read waits for it --, the next symbol's stream  \
+           bytes asked for before it, the remainder's steps across the quad and the stream bytes' extraction behind it) */ \
         asm volatile("v_sub_co_u32_e64 %[x1], %[c1], %[low], %[a1]\n\t"                                    \
                      "v_sub_co_u32_e64 %[x2], %[c2], %[low], %[a2]\n\t"                                    \
                      "v_sub_co_u32_e64 %[x3], %[c3], %[low], %[a3]\n\t"                                    \
                      "v_sub_co_u32_e64 %[x4], %[c4], %[low], %[a4]\n\t"                                    \
                      "v_subb_co_u32_e64 %[nd], %[c1], 4, 0, %[c1]\n\t"                                     \
-                     "v_min3_u32 %[rm], %[x1], %[x2], %[x3]\n\t"                                           \
                      "v_subb_co_u32_e64 %[nd], %[c2], %[nd], 0, %[c2]\n\t"                                 \
-                     "v_min3_u32 %[rm], %[rm], %[x4], %[low]\n\t"                                          \
                      "v_subb_co_u32_e64 %[nd], %[c3], %[nd], 0, %[c3]\n\t"                                 \
                      "v_subb_co_u32_e64 %[nd], %[c4], %[nd], 0, %[c4]\n\t"                                 \
-                     "v_min_u32_dpp %[rm], %[rm], %[rm] " RCX_QP1                                          \
                      "v_add_u32 %[bp], %[bp], %[k8]\n\t"                                                   \
-                     "v_add_u32_dpp %[nd], %[nd], %[nd] " RCX_QP1                                          \
-                     "v_min_u32_dpp %[rm], %[rm], %[rm] " RCX_QP2                                          \
                      "v_bfe_u32 %[ro], %[bp], 5, 5\n\t"                                                    \
-                     "v_add_u32_dpp %[nd], %[nd], %[nd] " RCX_QP2                                          \
-                     "v_lshl_add_u32 %[la], %[nd], 8, %[lvb]"                                              \
-                     : [nd] "=&v"(node_), [rm] "=&v"(rem_), [ro] "=&v"(ro_), [bp] "+v"(in.bp8), [la] "=&v"(la_), \
+                     "v_lshl_add_u32 %[ro], %[ro], 2, %[rb]"                                                \
+                     : [nd] "=&v"(node_), [ro] "=&v"(ro_), [bp] "+v"(in.bp8),                               \
                        [x1] "=&v"(x1_), [x2] "=&v"(x2_), [x3] "=&v"(x3_), [x4] "=&v"(x4_),                 \
                        [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_), [c4] "=&s"(c4_)                  \
                      : [low] "v"(in.low), [a1] "v"(a1_), [a2] "v"(a2_), [a3] "v"(a3_), [a4] "v"(a4_),      \
-                       [k8] "v"(k8_), [lvb] "v"(leaves_lds));                                              \
-        const RcxV4 l_ = *reinterpret_cast<const RcxLdsV4*>(la_);                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
+                       [k8] "v"(k8_), [rb] "v"(ring_lds));                                                 \
         {                                                                                                  \
-            const u32* at_ = in.ring + ro_; /* for the next symbol: never waited for */                    \
+            const RcxLdsU32* at_ = reinterpret_cast<const RcxLdsU32*>(ro_); /* for the next symbol */      \
             in.w0 = at_[0];                                                                                \
             in.w1 = at_[1];                                                                                \
         }                                                                                                  \
-        worst_node = worst_node > node_ ? worst_node : node_;                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        asm volatile("v_add_u32_dpp %[nd], %[nd], %[nd] " RCX_QP1                                          \
+                     "v_min3_u32 %[rm], %[x1], %[x2], %[x3]\n\t"                                           \
+                     "v_min3_u32 %[rm], %[rm], %[x4], %[low]\n\t"                                          \
+                     "v_add_u32_dpp %[nd], %[nd], %[nd] " RCX_QP2                                          \
+                     "v_lshl_add_u32 %[la], %[nd], 8, %[lvb]"                                              \
+                     : [nd] "+v"(node_), [rm] "=&v"(rem_), [la] "=&v"(la_)                                  \
+                     : [low] "v"(in.low), [x1] "v"(x1_), [x2] "v"(x2_), [x3] "v"(x3_), [x4] "v"(x4_),      \
+                       [lvb] "v"(leaves_lds));                                                             \
+        const RcxV4 l_ = *reinterpret_cast<const RcxLdsV4*>(la_);                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        asm volatile("v_min_u32_dpp %[rm], %[rm], %[rm] " RCX_QP1                                          \
+                     "v_max_u32 %[wn], %[wn], %[nd]"                                                       \
+                     : [rm] "+v"(rem_), [wn] "+v"(worst_node)                                               \
+                     : [nd] "v"(node_));                                                                   \
+        asm volatile("v_alignbit_b32 %[n4], %[w1], %[w0], %[bp]\n\t" /* the 4 bytes at bp8 ... */           \
+                     "v_min_u32_dpp %[rm], %[rm], %[rm] " RCX_QP2                                          \
+                     "v_perm_b32 %[n4], %[n4], %[n4], %[swap]"      /* ... first one on top */              \
+                     : [rm] "+v"(rem_), [n4] "=&v"(in.n4)                                                   \
+                     : [w0] "v"(in.w0), [w1] "v"(in.w1), [bp] "v"(in.bp8), [swap] "s"(0x00010203u));       \
         const u32 q1_ = l_.x * t_, q2_ = l_.y * t_, q3_ = l_.z * t_, q4_ = l_.w * t_;                      \
         u32 lo_, rg_, nb_, hi_, y1_, y2_, y3_, y4_;                                                        \
         asm volatile("v_sub_co_u32_e64 %[y1], %[c1], %[low], %[q1]\n\t"                                    \
@@ -752,17 +791,14 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_static_quad_k(const u8* __
                      "v_min_u32_dpp %[lo], %[lo], %[lo] " RCX_QP2                                          \
                      "v_add_u32_dpp %[nb], %[nb], %[nb] " RCX_QP2                                          \
                      "v_max_u32_dpp %[hi], %[hi], %[hi] " RCX_QP2                                          \
-                     "v_alignbit_b32 %[n4], %[w1], %[w0], %[bp]\n\t" /* the 4 bytes at bp8 ... */           \
                      "v_sub_u32 %[rg], %[lo], %[hi]\n\t"                                                   \
                      "v_lshl_add_u32 %[nb], %[nd], 4, %[nb]\n\t"     /* the symbol, in all four lanes */    \
-                     "v_perm_b32 %[n4], %[n4], %[n4], %[swap]\n\t"   /* ... first one on top */            \
                      "v_lshl_or_b32 %[word], %[nb], %[sh], %[word]"                                        \
                      : [lo] "=&v"(lo_), [rg] "=&v"(rg_), [nb] "=&v"(nb_), [hi] "=&v"(hi_), [y1] "=&v"(y1_), \
                        [y2] "=&v"(y2_), [y3] "=&v"(y3_), [y4] "=&v"(y4_), [c1] "=&s"(c1_), [c2] "=&s"(c2_),  \
-                       [c3] "=&s"(c3_), [c4] "=&s"(c4_), [word] "+v"(WORD), [n4] "=&v"(in.n4)              \
+                       [c3] "=&s"(c3_), [c4] "=&s"(c4_), [word] "+v"(WORD)                                  \
                      : [low] "v"(in.low), [q1] "v"(q1_), [q2] "v"(q2_), [q3] "v"(q3_), [q4] "v"(q4_),      \
-                       [rem] "v"(rem_), [nd] "v"(node_), [sh] "n"(SHIFT), [w0] "v"(in.w0), [w1] "v"(in.w1), \
-                       [bp] "v"(in.bp8), [swap] "s"(0x00010203u));                                         \
+                       [rem] "v"(rem_), [nd] "v"(node_), [sh] "n"(SHIFT));                                  \
         in.low = lo_;   /* :504 */                                                                         \
         in.range = rg_; /* :505 */                                                                         \
         least_range = least_range < rg_ ? least_range : rg_;                                               \
