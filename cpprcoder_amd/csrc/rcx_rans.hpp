@@ -1002,27 +1002,98 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_rans1_quad_k(const u8* __r
     const bool leader = live && in_use && j == 0;
     const u32 leaves_lds = (u32)reinterpret_cast<uintptr_t>(leaves);
 
-    // One symbol (cppans.h:556-561): get, the symbol of the slot, advance, renormalise by at most two bytes
-#define RCX_RANS1_SYMBOL(SYM)                                                                                \
+    const u32 ring_lds = (u32)reinterpret_cast<uintptr_t>(block_ring);
+    // One symbol (cppans.h:556-561): get, the symbol of the slot, advance, renormalise by at most two bytes.
+    // Written as instruction sequences like rcx_dec_quad_k / rcx_dec_static_quad_k (a lone wave: every compare result and
+    // every DPP source at least two instructions old, nothing but the node index's own steps in front of the leaf read);
+    // bounds at or below the slot are counted as the subtractions that do not borrow, slot - start is the unsigned
+    // minimum of the differences and the frequency minimum - maximum (mod 2^32).  What no later step of the chain
+    // needs is made by the NEXT symbol behind its leaf read (HP = 1: PWORD, PSHIFT are the earlier symbol's word and
+    // bit position) or by RCX_RANS1_FINISH: the symbol's byte, the stream position and the read of the ring pair there.
+    u32 p_nd_ = 0, p_nb_ = 0, p_r8_ = 0;
+#define RCX_QP1 "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define RCX_QP2 "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define RCX_R1_PREV_0
+#define RCX_R1_PREV_1 "\n\tv_lshl_add_u32 %[ps], %[pnd], 4, %[pnb]\n\t"                                             \
+                      "v_lshl_or_b32 %[pword], %[ps], %[psh], %[pword]"
+#define RCX_RANS1_SYMBOL(HP, PWORD, PSHIFT)                                                                  \
     {                                                                                                        \
-        const u32 slot_ = x & 16383u;                                                                        \
-        const u32 d1_ = slot_ - U1, d2_ = slot_ - U2, d3_ = slot_ - U3, d4_ = slot_ - U4_;                   \
-        const u32 c1_ = (U1 <= slot_ ? 1u : 0u) + (U2 <= slot_ ? 1u : 0u) + (U3 <= slot_ ? 1u : 0u) + (U4_ <= slot_ ? 1u : 0u); \
-        const u32 node_ = rcx_quad_sum(c1_);                                                                 \
-        const u32 rem_ = rcx_quad_min(rcx_umin(rcx_umin(rcx_umin(d1_, d2_), rcx_umin(d3_, d4_)), slot_));    \
-        const RcxV4 l_ = *reinterpret_cast<const RcxLdsV4*>(leaves_lds + (node_ << 8));                      \
-        const u32 e1_ = slot_ - l_.x, e2_ = slot_ - l_.y, e3_ = slot_ - l_.z, e4_ = slot_ - l_.w;            \
-        const u32 c2_ = (l_.x <= slot_ ? 1u : 0u) + (l_.y <= slot_ ? 1u : 0u) + (l_.z <= slot_ ? 1u : 0u) + (l_.w <= slot_ ? 1u : 0u); \
-        const u32 pos_ = rcx_quad_sum(c2_);                                                                  \
-        const u32 lo_ = rcx_quad_min(rcx_umin(rcx_umin(rcx_umin(e1_, e2_), rcx_umin(e3_, e4_)), rem_));      \
-        const u32 hi_ = rcx_quad_max(rcx_umax(rcx_umax(e1_, e2_), rcx_umax(e3_, e4_)));                      \
-        (SYM) = (node_ << 4) + pos_;                                                                         \
-        x = rcx_mul24(lo_ - hi_, x >> 14) + lo_; /* freq * (x >> 14) + slot - start (cppans.h:326) */        \
-        const u32 r8_ = x < (1u << 15) ? 16u : (x < (1u << 23) ? 8u : 0u); /* cppans.h:328-332 */            \
-        x = (u32)(((((u64)x) << 32) | in.n4) << r8_ >> 32);                                                  \
-        in.bp8 += r8_;                                                                                       \
-        in.fetch_pair();                                                                                     \
+        u32 slot_, xs_, node_, rem_, la_, ro_, x1_, x2_, x3_, x4_, ps_;                                      \
+        u64 c1_, c2_, c3_, c4_, cz_;                                                                         \
+        asm volatile("v_and_b32 %[sl], 0x3fff, %[x]\n\t"                                                     \
+                     "v_sub_co_u32_e64 %[x1], %[c1], %[sl], %[u1]\n\t"                                       \
+                     "v_sub_co_u32_e64 %[x2], %[c2], %[sl], %[u2]\n\t"                                       \
+                     "v_sub_co_u32_e64 %[x3], %[c3], %[sl], %[u3]\n\t"                                       \
+                     "v_sub_co_u32_e64 %[x4], %[c4], %[sl], %[u4]\n\t"                                       \
+                     "v_subb_co_u32_e64 %[nd], %[cz], 4, 0, %[c1]\n\t"                                       \
+                     "v_subb_co_u32_e64 %[nd], %[cz], %[nd], 0, %[c2]\n\t"                                   \
+                     "v_subb_co_u32_e64 %[nd], %[cz], %[nd], 0, %[c3]\n\t"                                   \
+                     "v_subb_co_u32_e64 %[nd], %[cz], %[nd], 0, %[c4]\n\t"                                   \
+                     "v_min3_u32 %[rm], %[x1], %[x2], %[x3]\n\t"                                             \
+                     "v_min3_u32 %[rm], %[rm], %[x4], %[sl]\n\t"                                             \
+                     "v_add_u32_dpp %[nd], %[nd], %[nd] " RCX_QP1                                            \
+                     "v_lshrrev_b32 %[xs], 14, %[x]\n\t"                                                     \
+                     "v_min_u32_dpp %[rm], %[rm], %[rm] " RCX_QP1                                            \
+                     "v_add_u32_dpp %[nd], %[nd], %[nd] " RCX_QP2                                            \
+                     "v_lshl_add_u32 %[la], %[nd], 8, %[lvb]"                                                \
+                     : [sl] "=&v"(slot_), [xs] "=&v"(xs_), [nd] "=&v"(node_), [rm] "=&v"(rem_), [la] "=&v"(la_), \
+                       [x1] "=&v"(x1_), [x2] "=&v"(x2_), [x3] "=&v"(x3_), [x4] "=&v"(x4_),                   \
+                       [c1] "=&s"(c1_), [c2] "=&s"(c2_), [c3] "=&s"(c3_), [c4] "=&s"(c4_), [cz] "=&s"(cz_)   \
+                     : [x] "v"(x), [u1] "v"(U1), [u2] "v"(U2), [u3] "v"(U3), [u4] "v"(U4_), [lvb] "v"(leaves_lds)); \
+        const RcxV4 l_ = *reinterpret_cast<const RcxLdsV4*>(la_);                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        asm volatile("v_min_u32_dpp %[rm], %[rm], %[rm] " RCX_QP2                                            \
+                     "v_add_u32 %[bp], %[bp], %[pr8]\n\t" /* the stream position after the earlier symbol */ \
+                     "v_bfe_u32 %[ro], %[bp], 5, 5\n\t"                                                      \
+                     "v_lshl_add_u32 %[ro], %[ro], 2, %[rb]"                                                 \
+                     RCX_R1_PREV_##HP                                                                        \
+                     : [rm] "+v"(rem_), [bp] "+v"(in.bp8), [ro] "=&v"(ro_), [ps] "=&v"(ps_), [pword] "+v"(PWORD) \
+                     : [pr8] "v"(p_r8_), [rb] "v"(ring_lds), [pnd] "v"(p_nd_), [pnb] "v"(p_nb_), [psh] "n"(PSHIFT)); \
+        {                                                                                                    \
+            const RcxLdsU32* at_ = reinterpret_cast<const RcxLdsU32*>(ro_); /* the bytes this symbol's renormalisation may take */ \
+            in.w0 = at_[0];                                                                                  \
+            in.w1 = at_[1];                                                                                  \
+        }                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        u32 lo_, rg_, nb_, hi_, y1_, y2_, y3_, y4_;                                                          \
+        asm volatile("v_sub_co_u32_e64 %[y1], %[c1], %[sl], %[lx]\n\t"                                       \
+                     "v_sub_co_u32_e64 %[y2], %[c2], %[sl], %[ly]\n\t"                                       \
+                     "v_sub_co_u32_e64 %[y3], %[c3], %[sl], %[lz]\n\t"                                       \
+                     "v_sub_co_u32_e64 %[y4], %[c4], %[sl], %[lw]\n\t"                                       \
+                     "v_subb_co_u32_e64 %[nb], %[c1], 4, 0, %[c1]\n\t"                                       \
+                     "v_min3_u32 %[lo], %[y1], %[y2], %[y3]\n\t"                                             \
+                     "v_subb_co_u32_e64 %[nb], %[c2], %[nb], 0, %[c2]\n\t"                                   \
+                     "v_max3_u32 %[hi], %[y1], %[y2], %[y3]\n\t"                                             \
+                     "v_subb_co_u32_e64 %[nb], %[c3], %[nb], 0, %[c3]\n\t"                                   \
+                     "v_min3_u32 %[lo], %[lo], %[y4], %[rem]\n\t"                                            \
+                     "v_subb_co_u32_e64 %[nb], %[c4], %[nb], 0, %[c4]\n\t"                                   \
+                     "v_max_u32 %[hi], %[hi], %[y4]\n\t"                                                     \
+                     "v_min_u32_dpp %[lo], %[lo], %[lo] " RCX_QP1                                            \
+                     "v_add_u32_dpp %[nb], %[nb], %[nb] " RCX_QP1                                            \
+                     "v_max_u32_dpp %[hi], %[hi], %[hi] " RCX_QP1                                            \
+                     "v_min_u32_dpp %[lo], %[lo], %[lo] " RCX_QP2                                            \
+                     "v_add_u32_dpp %[nb], %[nb], %[nb] " RCX_QP2                                            \
+                     "v_max_u32_dpp %[hi], %[hi], %[hi] " RCX_QP2                                            \
+                     "v_sub_u32 %[rg], %[lo], %[hi]"                                                         \
+                     : [lo] "=&v"(lo_), [rg] "=&v"(rg_), [nb] "=&v"(nb_), [hi] "=&v"(hi_), [y1] "=&v"(y1_),   \
+                       [y2] "=&v"(y2_), [y3] "=&v"(y3_), [y4] "=&v"(y4_), [c1] "=&s"(c1_), [c2] "=&s"(c2_),  \
+                       [c3] "=&s"(c3_), [c4] "=&s"(c4_)                                                      \
+                     : [sl] "v"(slot_), [lx] "v"(l_.x), [ly] "v"(l_.y), [lz] "v"(l_.z), [lw] "v"(l_.w),      \
+                       [rem] "v"(rem_));                                                                     \
+        p_nd_ = node_;                                                                                       \
+        p_nb_ = nb_;                                                                                         \
+        x = rcx_mul24(rg_, xs_) + lo_; /* freq * (x >> 14) + slot - start (cppans.h:326) */                   \
+        const u32 r8_ = (rcx_clz(x) - 1u) & 0x18u; /* cppans.h:328-332: x >= 2^7 here; 16 bits below 2^15, 8 below 2^23 */ \
         in.n4 = rcx_bswap(rcx_funnel_shr(in.w1, in.w0, in.bp8));                                             \
+        x = (u32)(((((u64)x) << 32) | in.n4) << r8_ >> 32);                                                  \
+        p_r8_ = r8_;                                                                                         \
+    }
+    // the byte of the last symbol decoded and the stream position behind it
+#define RCX_RANS1_FINISH(WORD, SHIFT)                                                                        \
+    {                                                                                                        \
+        (WORD) |= ((p_nd_ << 4) + p_nb_) << (SHIFT);                                                         \
+        in.bp8 += p_r8_;                                                                                     \
+        p_r8_ = 0;                                                                                           \
     }
 
     if (full) {
@@ -1031,16 +1102,15 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_rans1_quad_k(const u8* __r
         // vector instructions, not by memory -- so the pieces go one by one.)
         for (u32 i0 = 0; i0 < maxlen; i0 += 16) {
             in.topup();
-            u32 w[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (u32 k = 0; k < 16; ++k) {
-                u32 sym;
-                RCX_RANS1_SYMBOL(sym);
-                w[k >> 2] |= sym << (8 * (k & 3));
-            }
+            u32 w0_ = 0, w1_ = 0, w2_ = 0, w3_ = 0;
+            RCX_RANS1_SYMBOL(0, w0_, 0) RCX_RANS1_SYMBOL(1, w0_, 0) RCX_RANS1_SYMBOL(1, w0_, 8) RCX_RANS1_SYMBOL(1, w0_, 16)
+            RCX_RANS1_SYMBOL(1, w0_, 24) RCX_RANS1_SYMBOL(1, w1_, 0) RCX_RANS1_SYMBOL(1, w1_, 8) RCX_RANS1_SYMBOL(1, w1_, 16)
+            RCX_RANS1_SYMBOL(1, w1_, 24) RCX_RANS1_SYMBOL(1, w2_, 0) RCX_RANS1_SYMBOL(1, w2_, 8) RCX_RANS1_SYMBOL(1, w2_, 16)
+            RCX_RANS1_SYMBOL(1, w2_, 24) RCX_RANS1_SYMBOL(1, w3_, 0) RCX_RANS1_SYMBOL(1, w3_, 8) RCX_RANS1_SYMBOL(1, w3_, 16)
+            RCX_RANS1_FINISH(w3_, 24)
             if (leader) {
                 U4 o;
-                o.x = w[0], o.y = w[1], o.z = w[2], o.w = w[3];
+                o.x = w0_, o.y = w1_, o.z = w2_, o.w = w3_;
                 *reinterpret_cast<U4*>(out + i0) = o;
             }
         }
@@ -1048,13 +1118,19 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_rans1_quad_k(const u8* __r
         for (u32 i = 0; i < maxlen; ++i) {
             if ((i & 15u) == 0) in.topup();
             if (i < len) { // the 4 lanes of a quad agree
-                u32 sym;
-                RCX_RANS1_SYMBOL(sym);
+                u32 sym = 0;
+                RCX_RANS1_SYMBOL(0, sym, 0);
+                RCX_RANS1_FINISH(sym, 0);
                 if (leader) out[i] = (u8)sym;
             }
         }
     }
 #undef RCX_RANS1_SYMBOL
+#undef RCX_RANS1_FINISH
+#undef RCX_R1_PREV_0
+#undef RCX_R1_PREV_1
+#undef RCX_QP1
+#undef RCX_QP2
     // a valid stream holds every byte that was taken
     const u64 taken = RCX_RANS_HEADER - 4 + in.taken(); // QuadInput counts from 8 bytes into what it was given
     if (leader && taken > stream_len) rcx_flag(status, RCX_ST_CORRUPT, blk);
