@@ -684,45 +684,102 @@ __device__ __attribute__((noinline, cold)) u32 rcx_stage_carry(u32* ring_lane, u
     return extra != 0 && pos != 0 ? 1u : 0u; // (a carry out of the very first byte cannot happen: it starts as 0)
 }
 
-// The byte writer of EncLane (emit + flush), with the 4-byte words going to the block's LDS ring.
+// A carry ran through all of the newest four bytes (StagedWriter::emit; `acc` has it already): it goes on in the ring, byte
+// by byte.  First the two newest words go to their OWN slots as they were (the newest may so far only be in slot 64);
+// everything older is in the ring already, and current: a byte stops changing, these paths apart, once it is no longer
+// among the newest four.  Out of line: practically never on random data (tests/carry_runs.py builds the inputs).
+__device__ __attribute__((noinline, cold)) u32 rcx_stage_far_carry(u32* ring_lane, u64 acc_after, u32 pos8, u32 safe_from, u32 far)
+{
+    if (!far) return 0;
+    const u64 before = acc_after - 1;
+    const u32 sh8 = (0u - pos8) & 24u;
+    const u64 t = before << sh8;
+    const u32 w = (pos8 - 8u) >> 5; // the word of the newest byte
+    ring_lane[((w - 1u) % RCX_OUT_RING_WORDS) * RCX_LANES] = rcx_bswap((u32)(t >> 32));
+    ring_lane[(w % RCX_OUT_RING_WORDS) * RCX_LANES] = rcx_bswap((u32)t);
+    return rcx_stage_carry(ring_lane, pos8 >> 3, safe_from, 1u);
+}
+
+// The byte writer of the multi-wave encoders.  EncLane::emit gathers bytes in a register and lets four of them go when
+// it holds five or more; that is a dozen selects a symbol.  Here the register is a WINDOW -- the newest eight bytes of
+// the payload, newest lowest -- and the block's ring in LDS MIRRORS it: every symbol writes the two aligned words that hold
+// the newest five to eight bytes (one ds_write2st64_b32: consecutive words of a block are 64 dwords apart), whether
+// they are complete or not.  A carry (cpprcoder.h:767-781) is a 64-bit add on the window, made BEFORE the symbol's words
+// are written, so whatever it changes among the newest four bytes is simply written again; only a carry that runs
+// through all four of them -- the low half of the add overflows, which costs no instruction to notice -- has to go on
+// in the ring itself (rcx_stage_carry; practically never on random data, adversarial inputs: tests/carry_runs.py).
+// Ring slot 64 repeats slot 0 for the pair (63, 64): a word that lands there is the newest one, and it is written to
+// its own slot as the older word of the next pair before anything reads it (the drain keeps RCX_OUT_MARGIN bytes back,
+// finish() takes the newest word from the window).
 struct StagedWriter {
-    u64 acc;        // as EncLane::acc
-    u32 nacc8;
-    u32 pos;        // payload bytes handed to the ring so far
+    u64 acc;        // the newest 8 bytes of the payload as a number, newest byte lowest (before the stream: zeroes)
+    u32 pos8;       // 8 x the payload bytes produced so far (the reference's initial buffer_ = 0 is the first: EncLane)
+    u32 pos;        // pos8 / 8 as of the last chunk_begins() / chunk_ends()
     u32 safe_from;  // bytes below this may have been drained (pos at the start of the chunk - RCX_OUT_MARGIN)
     u32 redo;
-    u32* ring_lane; // word w of this block: ring_lane[(w % RCX_OUT_RING_WORDS) * RCX_LANES]
-    u32* dummy;     // takes the store of a symbol that completes no word
+    u32* ring_lane; // word w of this block: ring_lane[(w % RCX_OUT_RING_WORDS) * RCX_LANES]; slot RCX_OUT_RING_WORDS: see above
 
-    __device__ __forceinline__ void begin(u32* ring, u32* dummies, u32 lane)
+    __device__ __forceinline__ void begin(u32* ring, u32* /*slot 64 follows the ring*/, u32 lane)
     {
         acc = 0;
-        nacc8 = 8; // the reference's initial buffer_ = 0 is already "held" (see EncLane)
-        pos = 0;
+        pos8 = 8;
+        pos = 1;
         safe_from = 0;
         redo = 0;
         ring_lane = ring + lane;
-        dummy = dummies + lane;
+    }
+    __device__ __forceinline__ void chunk_begins()
+    {
+        pos = pos8 >> 3;
+        safe_from = pos > RCX_OUT_MARGIN ? pos - RCX_OUT_MARGIN : 0u;
+    }
+    __device__ __forceinline__ u32 chunk_ends()
+    {
+        pos = pos8 >> 3;
+        return pos;
+    }
+    // the two aligned words that hold the newest 5..8 bytes, from the window
+    __device__ __forceinline__ void mirror()
+    {
+        const u32 sh8 = (0u - pos8) & 24u;            // the window's end moved up to a word boundary
+        const u32 s0 = ((pos8 - 40u) >> 5) % RCX_OUT_RING_WORDS; // slot of the older word: ((pos - 1) / 4 - 1) mod 64
+        mirror_at(sh8, (u32)reinterpret_cast<uintptr_t>(ring_lane + s0 * RCX_LANES));
+    }
+    __device__ __forceinline__ void mirror_at(u32 sh8, u32 at_lds) // (an LDS address as a number: it passes through an asm statement)
+    {
+        const u64 t = acc << sh8;
+        RcxLdsU32* at = reinterpret_cast<RcxLdsU32*>(at_lds);
+        at[0] = rcx_bswap((u32)(t >> 32));
+        at[RCX_LANES] = rcx_bswap((u32)t);
     }
     __device__ __forceinline__ void emit(u32 rec)
     {
+        const u32 lo0 = (u32)acc;
+        const u32 lo1 = lo0 + (rec & 1u);                  // cpprcoder.h:767-781
+        const bool far = lo1 < lo0;                        // ... through all of the newest four bytes
+        // (where the words go depends on the position alone: worked out between the two halves of the add, whose second
+        // half may not follow the first at once)
+        u32 sh8 = (0u - pos8) & 24u;
+        u32 at = (u32)reinterpret_cast<uintptr_t>(ring_lane + (((pos8 - 40u) >> 5) % RCX_OUT_RING_WORDS) * RCX_LANES);
+        asm volatile("" : "+v"(sh8), "+v"(at));
+        acc = ((u64)((u32)(acc >> 32) + (far ? 1u : 0u)) << 32) | lo1;
+        if (rcx_any(far)) redo |= rcx_stage_far_carry(ring_lane, acc, pos8, safe_from, far ? 1u : 0u);
+        mirror_at(sh8, at);
         const u32 k8 = rec & 0x18u;
-        acc += rec & 1u;                                     // cpprcoder.h:767-781, resolved lazily
-        acc = (acc << k8) | (((u64)rec << k8) >> 32);
-        nacc8 += k8;
-        // with 5..7 bytes held: the 4 oldest leave (EncLane::flush, branch-free)
-        const bool due = nacc8 >= 40;
-        const u32 keep8 = (nacc8 - 32) & 31u;
-        const u32 acc_lo = (u32)acc, acc_hi = (u32)(acc >> 32);
-        const u32 word = rcx_funnel_shr(acc_hi, acc_lo, keep8);
-        const u32 extra = due ? acc_hi >> keep8 : 0u;
-        if (rcx_any(extra != 0)) redo |= rcx_stage_carry(ring_lane, pos, safe_from, extra);
-        u32* at = due ? ring_lane + ((pos >> 2) % RCX_OUT_RING_WORDS) * RCX_LANES : dummy;
-        *at = rcx_bswap(word);
-        const u32 kept = acc_lo & ((1u << keep8) - 1u);
-        acc = due ? (u64)kept : acc;
-        nacc8 -= due ? 32u : 0u;
-        pos += due ? 4u : 0u;
+        acc = (acc << k8) | __builtin_amdgcn_ubfe(rec, 32u - k8, k8); // the k8 / 8 bytes that leave through the top of low
+        pos8 += k8;
+    }
+    // After the last symbol: the words below the newest one are in the ring (returns how many bytes that is); the newest
+    // 1..4 bytes are handed over as EncLane's held bytes.
+    __device__ __forceinline__ u32 finish(EncLane& enc)
+    {
+        mirror();
+        pos = pos8 >> 3;
+        const u32 flushed = ((pos - 1u) >> 2) << 2;
+        enc.nacc8 = 8u * (pos - flushed);
+        enc.acc = acc & ((1ull << enc.nacc8) - 1ull);
+        enc.pos = flushed;
+        return flushed;
     }
 };
 
@@ -795,7 +852,7 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
             if (k >= 2) {
                 const u32* rs2 = ring2 + ((k - 2) & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
                 u32 ra_next = rs2[0], rb_next = rs2[RCX_LANES]; // (pairs: one ds_read2st64_b32)
-                wr.safe_from = wr.pos > RCX_OUT_MARGIN ? wr.pos - RCX_OUT_MARGIN : 0u;
+                wr.chunk_begins();
 #pragma unroll
                 for (u32 s = 0; s < RCX_MC_CHUNK; s += 2) {
                     const u32 ra = ra_next, rb = rb_next;
@@ -803,7 +860,7 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
                     wr.emit(ra);
                     wr.emit(rb);
                 }
-                out_pos[lane] = wr.pos; // for the drain of the next iteration
+                out_pos[lane] = wr.chunk_ends(); // for the drain of the next iteration
             }
         } else {
           // ---- drain: whole 16-byte pieces below (the writer's position one barrier ago - margin) ----
@@ -1042,12 +1099,10 @@ __global__ __launch_bounds__(RCX_MC5_THREADS) void rcx_enc_mc5_k(const u8* __res
     if (wave == 1 && live) {
         // what is still in the ring, then cpprcoder.h:744-762 as in the one-wave coder
         u32 at = out_drained[lane];
-        const u32 end = wr.pos < cap ? wr.pos : cap;
+        const u32 flushed = wr.finish(enc);
+        const u32 end = flushed < cap ? flushed : cap;
         for (; at < end; at += 4) *reinterpret_cast<u32*>(payload + at) = wr.ring_lane[((at >> 2) % RCX_OUT_RING_WORDS) * RCX_LANES];
         enc.low = final_low[lane];
-        enc.acc = wr.acc;
-        enc.nacc8 = wr.nacc8;
-        enc.pos = wr.pos;
         const u32 bytes = enc.finish();
         sizes[blk] = enc.overflow ? (u32)slot : bytes;
         if (enc.overflow) rcx_flag(status, RCX_ST_CAPACITY, blk);

@@ -249,7 +249,7 @@ __device__ __forceinline__ void rcx_static3_pipeline(u32 wave, u32 lane, u32 len
             if (k >= 2) {
                 const u32* rs2 = ring2 + ((k - 2) & 1u) * (RCX_MC_CHUNK * RCX_LANES) + lane;
                 u32 ra_next = rs2[0], rb_next = rs2[RCX_LANES];
-                wr.safe_from = wr.pos > RCX_OUT_MARGIN ? wr.pos - RCX_OUT_MARGIN : 0u;
+                wr.chunk_begins();
 #pragma unroll
                 for (u32 s = 0; s < RCX_MC_CHUNK; s += 2) {
                     const u32 ra = ra_next, rb = rb_next;
@@ -257,7 +257,7 @@ __device__ __forceinline__ void rcx_static3_pipeline(u32 wave, u32 lane, u32 len
                     wr.emit(ra);
                     wr.emit(rb);
                 }
-                out_pos[lane] = wr.pos;
+                out_pos[lane] = wr.chunk_ends();
             }
         } else {
             // ---- drain (see rcx_mc5_pipeline: the reads here, the stores between the wait for this chunk's input and the
@@ -455,12 +455,10 @@ __global__ __launch_bounds__(RCX_ST3_THREADS) void rcx_enc_static3_k(const u8* _
     rcx_lds_barrier();
     if (wave == 1 && live) {
         u32 at2 = out_drained[lane];
-        const u32 end = wr.pos < cap ? wr.pos : cap;
+        const u32 flushed = wr.finish(enc);
+        const u32 end = flushed < cap ? flushed : cap;
         for (; at2 < end; at2 += 4) *reinterpret_cast<u32*>(payload + at2) = wr.ring_lane[((at2 >> 2) % RCX_OUT_RING_WORDS) * RCX_LANES];
         enc.low = final_low[lane];
-        enc.acc = wr.acc;
-        enc.nacc8 = wr.nacc8;
-        enc.pos = wr.pos;
         if (enc.low == 0xFFFFFFFFu) enc.acc += 1; // cpprcoder.h:439-443
         const u32 bytes = enc.finish() + (RCX_STATIC_HEADER - 4);
         sizes[blk] = enc.overflow ? (u32)slot : bytes;
