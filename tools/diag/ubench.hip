@@ -94,6 +94,31 @@ BENCH_KERNEL(k_t_wr128_rd128, TSET, V8 "ds_write_b128 v40, v[44:47]\n\tds_read_b
 BENCH_KERNEL(k_t_waitcnt, TSET, V8 "s_waitcnt lgkmcnt(0)")
 BENCH_KERNEL(k_t_sdwa, TSET, V8 "v_cndmask_b32_sdwa %[d], %[d], %[b], vcc dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_0")
 
+// Vector memory instructions whose 64 lanes go to 64 different places (one 16-byte piece per lane, the lanes STRIDE bytes
+// apart: 65536 = the coders' one-block-per-lane access, 16 = adjacent pieces): what does ONE of them cost a lone wave in a
+// stream of vector instructions (eight dependent adds per copy), results never waited for?  `sink` must hold 4 MiB + 1 KiB.
+#define VMEM_KERNEL(name, STRIDE, body)                                                           \
+    __global__ void name(unsigned long long* out, unsigned* sink)                                 \
+    {                                                                                             \
+        unsigned v0 = threadIdx.x, v1 = 3;                                                        \
+        unsigned long long ad = (unsigned long long)sink + (unsigned long long)(threadIdx.x & 63) * (STRIDE); \
+        unsigned long long t0, t1;                                                                \
+        asm volatile("v_mov_b32 v44, 1\n\tv_mov_b32 v45, 1\n\tv_mov_b32 v46, 1\n\tv_mov_b32 v47, 1\n\t"   \
+                     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %[t0]\n\ts_waitcnt lgkmcnt(0)\n\t"     \
+                     ".rept " STR(REPS) "\n\t" V8 body "\n\t.endr\n\t"                                \
+                     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %[t1]\n\ts_waitcnt lgkmcnt(0)"       \
+                     : [t0] "=&s"(t0), [t1] "=&s"(t1), [a] "+v"(v0), [b] "+v"(v1)                  \
+                     : [ad] "v"(ad)                                                               \
+                     : "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "memory");        \
+        if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;                                \
+        sink[0] = v0;                                                                             \
+    }
+VMEM_KERNEL(k_v_ld_scatter, 65536, "global_load_dwordx4 v[48:51], %[ad], off")
+VMEM_KERNEL(k_v_ld_contig, 16, "global_load_dwordx4 v[48:51], %[ad], off")
+VMEM_KERNEL(k_v_st_scatter, 65536, "global_store_dwordx4 %[ad], v[44:47], off")
+VMEM_KERNEL(k_v_st_contig, 16, "global_store_dwordx4 %[ad], v[44:47], off")
+VMEM_KERNEL(k_v_st4_scatter, 65536, "global_store_dword %[ad], v44, off")
+
 // ---------------------------------------------------------------------------------------------
 // The quad decoder's LDS pattern: per "symbol" one broadcast ds_read2_b64, PRE dependent VALU ops, a
 // ds_read_b128 whose address differs per quad (16 distinct 64-byte windows), a ds_read2_b32, GAP
@@ -291,7 +316,7 @@ int main(int argc, char** argv)
     unsigned long long* out;
     unsigned* sink;
     hipMalloc(&out, 8);
-    hipMalloc(&sink, 4096 * 4);
+    hipMalloc(&sink, (4 << 20) + 4096 * 4);
     const char* only = argc > 3 ? argv[3] : nullptr;
 #define C(k, per) {#k, k, per}
     std::vector<Case> cases = {C(k_add_dep, 1), C(k_add_indep, 2), C(k_mul24, 1), C(k_mad64, 1), C(k_mulhi, 1), C(k_mullo, 1),
@@ -301,7 +326,7 @@ int main(int argc, char** argv)
                                C(k_branch_taken, 2), C(k_branch_not, 2), C(k_cbranch_taken, 2), C(k_cvt_rcp, 2), C(k_ffbh, 1),
                                C(k_readlane, 2), C(k_salu, 1), C(k_valu_salu, 2),
                                C(k_t_none, 8), C(k_t_rd_b32, 9), C(k_t_rd_b64, 9), C(k_t_rd_b128, 9), C(k_t_rd2_b32, 9), C(k_t_rd2_b64, 9), C(k_t_wr_b32, 9), C(k_t_wr_b8, 9),
-                               C(k_t_wr_b64, 9), C(k_t_wr_b128, 9), C(k_t_add, 9), C(k_t_add_rd128, 10), C(k_t_wr128_rd128, 10), C(k_t_waitcnt, 9), C(k_t_sdwa, 9),
+                               C(k_t_wr_b64, 9), C(k_t_wr_b128, 9), C(k_t_add, 9), C(k_t_add_rd128, 10), C(k_t_wr128_rd128, 10), C(k_t_waitcnt, 9), C(k_t_sdwa, 9), C(k_v_ld_scatter, 9), C(k_v_ld_contig, 9), C(k_v_st_scatter, 9), C(k_v_st_contig, 9), C(k_v_st4_scatter, 9),
                                C(k_sym_gap0, 65), C(k_sym_gap4, 69), C(k_sym_gap8, 73), C(k_sym_gap12, 77), C(k_sym_gap16, 81), C(k_sym_gap24, 89),
                                C(k_sym_gap32, 97), C(k_sym_gap12_noatom, 76), C(k_sym_gap12_b64, 77), C(k_sym_gap0_b64, 65),
                                C(k_blk_a, 17), C(k_blk_u, 9), C(k_blk_c, 36), C(k_blk_auc, 62), C(k_loop_auc, 62), C(k_loop_add62, 62), C(k_loop_min3_62, 62),
