@@ -797,6 +797,7 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
     U4 piece_ahead;
     piece_ahead.x = piece_ahead.y = piece_ahead.z = piece_ahead.w = 0;
     if (FULL && wave >= 2 && nchunks > 0) piece_ahead = *reinterpret_cast<const U4*>(in);
+    u32 l3a = 64, l3b = 128, l3c = 192; // wave 2: the level-3 sums (cpprcoder.h:1094-1132: every count 1)
     for (u32 k = 0; k <= nchunks + 1; ++k) {
         if (wave == 0) {
             // ---- arithmetic: chunk k-1, records into ring2[(k-1)&1] ----
@@ -941,12 +942,8 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
 #define RCX_M2_ISSUE(T)                                                       \
     {                                                                         \
         const u32 c_ = rcx_byte_of(piece, (T));                               \
-        ga[T] = tree.group(RCX_G_L3);                                         \
         gb[T] = tree.group(RCX_G_L2 + (c_ >> 6));                             \
-        if (FULL || i0 + (T) < len) {                                         \
-            tree.bump(RCX_G_L3, c_ >> 6);                                     \
-            tree.bump(RCX_G_L2 + (c_ >> 6), (c_ >> 4) & 3);                   \
-        }                                                                     \
+        if (FULL || i0 + (T) < len) tree.bump(RCX_G_L2 + (c_ >> 6), (c_ >> 4) & 3); \
     }
 #pragma unroll
                 for (u32 t = 0; t < RCX_MODEL_AHEAD; ++t) RCX_M2_ISSUE(t);
@@ -954,7 +951,29 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
                 for (u32 s = 0; s < RCX_MC_CHUNK; ++s) {
                     if (s + RCX_MODEL_AHEAD < RCX_MC_CHUNK) RCX_M2_ISSUE(s + RCX_MODEL_AHEAD);
                     const u32 cc = rcx_byte_of(piece, s);
-                    const u32 sum32 = rcx_pre4(ga[s], cc >> 6) + rcx_pre4(gb[s], (cc >> 4) & 3);
+                    // Level 3 -- one group per block -- lives in registers as three prefix sums (symbols below 64, 128,
+                    // 192 so far): three compares serve both the select and the update (an LDS read, a ds_add and the
+                    // masked sum cost this wave, the kernel's busiest, 20 cycles a symbol more).
+                    u32 cum3;
+                    if (FULL) {
+                        u64 m1_, m2_, m3_, cz_;
+                        asm volatile("v_cmp_gt_u32_e64 %[m3], %[k192], %[c]\n\t" /* (no literals in this encoding: 192, 128 from registers) */
+                                     "v_cmp_gt_u32_e64 %[m2], %[k128], %[c]\n\t"
+                                     "v_cmp_gt_u32_e64 %[m1], 64, %[c]\n\t"
+                                     "v_cndmask_b32_e64 %[x], %[pc], %[pb], %[m3]\n\t"
+                                     "v_cndmask_b32_e64 %[x], %[x], %[pa], %[m2]\n\t"
+                                     "v_cndmask_b32_e64 %[x], %[x], 0, %[m1]\n\t"
+                                     "v_addc_co_u32_e64 %[pc], %[cz], %[pc], 0, %[m3]\n\t"
+                                     "v_addc_co_u32_e64 %[pb], %[cz], %[pb], 0, %[m2]\n\t"
+                                     "v_addc_co_u32_e64 %[pa], %[cz], %[pa], 0, %[m1]"
+                                     : [x] "=&v"(cum3), [pa] "+v"(l3a), [pb] "+v"(l3b), [pc] "+v"(l3c), [m1] "=&s"(m1_), [m2] "=&s"(m2_),
+                                       [m3] "=&s"(m3_), [cz] "=&s"(cz_)
+                                     : [c] "v"(cc), [k192] "s"(192u), [k128] "s"(128u));
+                    } else {
+                        cum3 = cc < 64u ? 0u : (cc < 128u ? l3a : (cc < 192u ? l3b : l3c));
+                        if (i0 + s < len) l3a += cc < 64u ? 1u : 0u, l3b += cc < 128u ? 1u : 0u, l3c += cc < 192u ? 1u : 0u;
+                    }
+                    const u32 sum32 = cum3 + rcx_pre4(gb[s], (cc >> 4) & 3);
                     if (FULL) { // (pairs: one ds_write2st64_b32)
                         if ((s & 1u) == 0) held = sum32;
                         else ws[RCX_RING_AT(s - 1, 0)] = held, ws[RCX_RING_AT(s, 0)] = sum32;
@@ -1072,8 +1091,6 @@ __global__ __launch_bounds__(RCX_MC5_THREADS) void rcx_enc_mc5_k(const u8* __res
         if (live) enc.begin(wave_slots, lane * (u32)slot, (u32)slot, len);
         out_pos[lane] = 0;
     } else if (wave == 2) { // cpprcoder.h:1094-1132: every count 1
-        v.x = v.y = v.z = v.w = 64;
-        tree.store(RCX_G_L3, v);
         v.x = v.y = v.z = v.w = 16;
         for (u32 g = RCX_G_L2; g < RCX_G_L1; ++g) tree.store(g, v);
     } else if (wave == 4) {
