@@ -700,6 +700,48 @@ __device__ __attribute__((noinline, cold)) u32 rcx_stage_far_carry(u32* ring_lan
     return rcx_stage_carry(ring_lane, pos8 >> 3, safe_from, 1u);
 }
 
+// The drain of a block's output ring (both multi-wave encoders): `piece` = the four ring words at `drained`, read earlier;
+// it leaves if it lies below `lim`.  The predicated store is written out -- the compiler's version of
+// `if (...) store` around three conditional pieces was forty instructions of execution-mask bookkeeping a chunk, on the
+// wave that shares its SIMD with the arithmetic wave -- and a block that is more than one piece behind (a chunk makes 48
+// bytes at most) goes out of line, where a loop may be a loop (in front of one the compiler waits for every store in flight).
+__device__ __attribute__((noinline, cold)) u32 rcx_drain_more(const u32* ring_lane, u8* payload, u32 drained, u32 lim, bool live)
+{
+    while (__any(live && drained + 16 <= lim)) {
+        if (live && drained + 16 <= lim) {
+            const u32* w = ring_lane + ((drained >> 2) % RCX_OUT_RING_WORDS) * RCX_LANES; // (drained is a multiple of 16)
+            RcxU4Unaligned piece;
+            piece.x = w[0];
+            piece.y = w[RCX_LANES];
+            piece.z = w[2 * RCX_LANES];
+            piece.w = w[3 * RCX_LANES];
+            *reinterpret_cast<RcxU4Unaligned*>(payload + drained) = piece;
+            drained += 16;
+        }
+    }
+    return drained;
+}
+__device__ __forceinline__ u32 rcx_drain_piece(const u32* ring_lane, u8* payload, u32 drained, u32 lim, bool live, const RcxU4Unaligned& piece)
+{
+    const bool go = live && drained + 16 <= lim;
+    {
+        const u64 lanes = __ballot(go);
+        u8* at = payload + drained;
+        RcxV4 data;
+        data.x = piece.x, data.y = piece.y, data.z = piece.z, data.w = piece.w;
+        u64 saved;
+        asm volatile("s_and_saveexec_b64 %[sv], %[go]\n\t"
+                     "global_store_dwordx4 %[at], %[data], off\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [sv] "=&s"(saved)
+                     : [go] "s"(lanes), [at] "v"(at), [data] "v"(data)
+                     : "memory");
+    }
+    drained += go ? 16u : 0u;
+    if (rcx_any(live && drained + 16 <= lim)) drained = rcx_drain_more(ring_lane, payload, drained, lim, live);
+    return drained;
+}
+
 // The byte writer of the multi-wave encoders.  EncLane::emit gathers bytes in a register and lets four of them go when
 // it holds five or more; that is a dozen selects a symbol.  Here the register is a WINDOW -- the newest eight bytes of
 // the payload, newest lowest -- and the block's ring in LDS MIRRORS it: every symbol writes the two aligned words that hold
@@ -883,25 +925,7 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
           // every store in flight, and a store's round trip is a quarter of a chunk's time.)
           auto drain_store = [&]() {
             const u32 limit = drain_p > RCX_OUT_MARGIN ? (drain_p - RCX_OUT_MARGIN) & ~15u : 0u;
-            if (live && drained + 16 <= limit && drained + 16 <= cap) {
-                *reinterpret_cast<RcxU4Unaligned*>(payload + drained) = drain_piece;
-                drained += 16;
-            }
-#pragma unroll
-            for (u32 more = 0; more < 2; ++more) {
-                if (__any(live && drained + 16 <= limit && drained + 16 <= cap)) { // a block that is more than one piece behind
-                    if (live && drained + 16 <= limit && drained + 16 <= cap) {
-                        const u32* w = wr.ring_lane + ((drained >> 2) % RCX_OUT_RING_WORDS) * RCX_LANES;
-                        RcxU4Unaligned piece;
-                        piece.x = w[0];
-                        piece.y = w[RCX_LANES];
-                        piece.z = w[2 * RCX_LANES];
-                        piece.w = w[3 * RCX_LANES];
-                        *reinterpret_cast<RcxU4Unaligned*>(payload + drained) = piece;
-                        drained += 16;
-                    }
-                }
-            }
+            drained = rcx_drain_piece(wr.ring_lane, payload, drained, limit < cap ? limit : cap, live, drain_piece);
           };
           if (k >= nchunks && wave == RCX_DRAIN_WAVE) drain_store();
           if (k < nchunks) {

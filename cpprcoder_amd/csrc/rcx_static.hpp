@@ -273,25 +273,7 @@ __device__ __forceinline__ void rcx_static3_pipeline(u32 wave, u32 lane, u32 len
             }
             auto drain_store = [&]() {
                 const u32 limit = drain_p > RCX_OUT_MARGIN ? (drain_p - RCX_OUT_MARGIN) & ~15u : 0u;
-                if (live && drained + 16 <= limit && drained + 16 <= cap) {
-                    *reinterpret_cast<RcxU4Unaligned*>(payload + drained) = drain_piece;
-                    drained += 16;
-                }
-#pragma unroll
-                for (u32 more = 0; more < 2; ++more) {
-                    if (__any(live && drained + 16 <= limit && drained + 16 <= cap)) {
-                        if (live && drained + 16 <= limit && drained + 16 <= cap) {
-                            const u32* w = wr.ring_lane + ((drained >> 2) % RCX_OUT_RING_WORDS) * RCX_LANES;
-                            RcxU4Unaligned piece;
-                            piece.x = w[0];
-                            piece.y = w[RCX_LANES];
-                            piece.z = w[2 * RCX_LANES];
-                            piece.w = w[3 * RCX_LANES];
-                            *reinterpret_cast<RcxU4Unaligned*>(payload + drained) = piece;
-                            drained += 16;
-                        }
-                    }
-                }
+                drained = rcx_drain_piece(wr.ring_lane, payload, drained, limit < cap ? limit : cap, live, drain_piece);
             };
             if (k >= nchunks) drain_store();
             // ---- lookups: chunk k ----
