@@ -18,6 +18,7 @@
 //
 // Included at the end of rcx_kernels.hpp.
 #pragma once
+#include "rcx_divtab.hpp"
 
 #define RCX_RANS_HEADER 1032u /* 258 dwords: cppans.h:521, :598 */
 #define RCX_RANS_BLOCKS 8     /* blocks per wave */
@@ -147,6 +148,24 @@ __device__ __forceinline__ void rcx_rans_write_header(u8* at, u32 n, const u32* 
     }
 }
 
+// The eight-state encoder's table: 8 bytes per symbol, shift | inc << 5 | start << 6 | freq << 19 (start and freq can both be
+// 4096: 13 bits each) and the multiplier of
+// x / freq = mulhi(x + inc, mul) >> shift (rcx_make_div_entry: exact for every 32-bit x; x + 1 cannot wrap here, a state is
+// below freq << 20).  It takes the place of cum[] and table[] once the model is built.
+__device__ __forceinline__ void rcx_rans_write_header_ent(u8* at, u32 n, const u64* ent, u32 total, u32 j)
+{
+    for (u32 i = j; i < 258; i += 8) {
+        const u32 v = i == 0 ? n : (i == 257 ? total : ((u32)ent[i - 1] >> 6) & 0x1FFFu);
+        if ((reinterpret_cast<uintptr_t>(at) & 3u) == 0) reinterpret_cast<u32*>(at)[i] = v;
+        else {
+            at[4 * i + 0] = (u8)v;
+            at[4 * i + 1] = (u8)(v >> 8);
+            at[4 * i + 2] = (u8)(v >> 16);
+            at[4 * i + 3] = (u8)(v >> 24);
+        }
+    }
+}
+
 // ===========================================================================
 // Encode, pass 1: every block's stream ends at the end of its slot; sizes[b] = its length, starts[b] = where it
 // begins in the slot.  WORD = the eight-state format.
@@ -170,6 +189,21 @@ __global__ __launch_bounds__(256) void rcx_enc_rans_k(const u8* __restrict__ src
 
     if (len != 0) rcx_rans_model<PROB_BITS>(cum, table, in, len, j, (reinterpret_cast<uintptr_t>(in) & 15u) == 0);
     // (a wave's LDS operations execute in order and an octet lives in one wave: no barrier needed)
+    u64* const ent = reinterpret_cast<u64*>(cum); // WORD: see rcx_rans_write_header_ent
+    if (WORD) {
+        // lane j turns symbols 32j .. 32j+31 over: all of them read before any is written (the new table lies over the old)
+        u32 old[32];
+#pragma unroll
+        for (u32 i = 0; i < 32; ++i) old[i] = len != 0 ? table[32 * j + i] : 0u;
+        rcx_octet_sync();
+#pragma unroll 4
+        for (u32 i = 0; i < 32; ++i) {
+            const u32 freq = old[i] >> 16, start = old[i] & 0xFFFFu;
+            const DivEntry d = rcx_make_div_entry(freq ? freq : 1u);
+            ent[32 * j + i] = ((u64)d.mul << 32) | d.shift | (d.add ? 32u : 0u) | (start << 6) | (freq << 19);
+        }
+        rcx_octet_sync();
+    }
 
     u8* const slot_base = slots + blk * slot; // only dereferenced by live lanes
     u32 ptr = (u32)slot;                      // byte offset in the slot: everything from here up is written
@@ -195,8 +229,8 @@ __global__ __launch_bounds__(256) void rcx_enc_rans_k(const u8* __restrict__ src
         // kept the wave waiting (profiles/r03_rans8_pmc.json: 45 % of its cycles in s_waitcnt).
 #define RCX_RANS8_PUT(ACTIVE, SYM)                                                                                   \
     {                                                                                                                \
-        const u32 e_ = table[(SYM)];                                                                                 \
-        const u32 freq_ = e_ >> 16, start_ = e_ & 0xFFFFu;                                                           \
+        const u64 e_ = ent[(SYM)];                                                                                   \
+        const u32 e0_ = (u32)e_, freq_ = e0_ >> 19, start_ = (e0_ >> 6) & 0x1FFFu;                                    \
         const u32 x_max_ = freq_ << 20; /* cppans.h:357: ((2^16 >> 12) << 16) * freq in u32 -- wraps to 0 for freq = 4096 */ \
         const bool emit_ = (ACTIVE) && x_max_ <= x;                                                                  \
         const u32 mask_ = rcx_octet_ballot(emit_, lane);                                                             \
@@ -207,8 +241,8 @@ __global__ __launch_bounds__(256) void rcx_enc_rans_k(const u8* __restrict__ src
         u8* const where_ = (emit_ && !overflow) ? ring + ((ptr + 2 * before_) & 255u) : ring + 256 + 2 * j;         \
         *reinterpret_cast<unsigned short*>(where_) = (unsigned short)(x & 0xFFFFu);                                  \
         x = emit_ ? x >> 16 : x;                                                                                     \
-        u32 rem_;                                                                                                    \
-        const u32 q_ = rcx_div_small_quotient(x, freq_ ? freq_ : 1u, rem_); /* cppans.h:363 */                       \
+        const u32 q_ = __umulhi(x + ((e0_ >> 5) & 1u), (u32)(e_ >> 32)) >> (e0_ & 31u); /* x / freq, cppans.h:363 */ \
+        const u32 rem_ = x - rcx_mul24(q_, freq_); /* (q < 2^20, freq <= 2^12) */                                    \
         x = (ACTIVE) ? (q_ << 12) + rem_ + start_ : x;                                                               \
     }
         // whole 16-byte pieces of the ring go to memory, the highest first: lane k takes the k-th (at most 8 are due: eight
@@ -345,7 +379,8 @@ __global__ __launch_bounds__(256) void rcx_enc_rans_k(const u8* __restrict__ src
         }
     }
     ptr -= RCX_RANS_HEADER;
-    rcx_rans_write_header(slot_base + ptr, len, cum, j);
+    if (WORD) rcx_rans_write_header_ent(slot_base + ptr, len, ent, 1u << PROB_BITS, j);
+    else rcx_rans_write_header(slot_base + ptr, len, cum, j);
     if (j == 0) {
         sizes[blk] = overflow ? 0u : (u32)slot - ptr;
         starts[blk] = overflow ? 0u : ptr;
