@@ -699,7 +699,20 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_static_quad_k(const u8* __
 #define RCX_QP2 "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
     // One symbol (instruction sequences as in rcx_dec_quad_k: no compare result or DPP source is used before two
     // other instructions have been issued).  Every lane of the quad ORs the symbol into WORD at bit SHIFT.
-#define RCX_SQUAD_SYMBOL(WORD, SHIFT)                                                                      \
+    // (as in rcx_dec_quad_k, what the coder state does not need -- the symbol's byte, the watch on the smallest range -- is
+    // made by the NEXT symbol behind its leaf read: HP = 1, PWORD / PSHIFT = the earlier symbol's word and bit position;
+    // RCX_SQUAD_FINISH makes the last one)
+    u32 p_nd_ = 0, p_nb_ = 0, p_rg_ = 0xFFFFFFFFu;
+#define RCX_SQ_PREV_0
+#define RCX_SQ_PREV_1 "\n\tv_lshl_add_u32 %[ps], %[pnd], 4, %[pnb]\n\t"                                             \
+                      "v_min_u32 %[lr], %[lr], %[prg]\n\t"                                                           \
+                      "v_lshl_or_b32 %[pword], %[ps], %[psh], %[pword]"
+#define RCX_SQUAD_FINISH(WORD, SHIFT)                                                                      \
+    {                                                                                                      \
+        (WORD) |= ((p_nd_ << 4) + p_nb_) << (SHIFT);                                                       \
+        least_range = least_range < p_rg_ ? least_range : p_rg_;                                           \
+    }
+#define RCX_SQUAD_SYMBOL(HP, PWORD, PSHIFT)                                                                \
     {                                                                                                      \
         const u32 k8_ = rcx_clz(in.range) & 0x18u; /* cpprcoder.h:511-516, for the previous symbol */      \
         in.low = (u32)((((u64)in.low << 32) | in.n4) << k8_ >> 32);                                        \
@@ -746,11 +759,14 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_static_quad_k(const u8* __
                      "v_max_u32 %[wn], %[wn], %[nd]"                                                       \
                      : [rm] "+v"(rem_), [wn] "+v"(worst_node)                                               \
                      : [nd] "v"(node_));                                                                   \
+        u32 ps_;                                                                                           \
         asm volatile("v_alignbit_b32 %[n4], %[w1], %[w0], %[bp]\n\t" /* the 4 bytes at bp8 ... */           \
                      "v_min_u32_dpp %[rm], %[rm], %[rm] " RCX_QP2                                          \
                      "v_perm_b32 %[n4], %[n4], %[n4], %[swap]"      /* ... first one on top */              \
-                     : [rm] "+v"(rem_), [n4] "=&v"(in.n4)                                                   \
-                     : [w0] "v"(in.w0), [w1] "v"(in.w1), [bp] "v"(in.bp8), [swap] "s"(0x00010203u));       \
+                     RCX_SQ_PREV_##HP                                                                      \
+                     : [rm] "+v"(rem_), [n4] "=&v"(in.n4), [ps] "=&v"(ps_), [lr] "+v"(least_range), [pword] "+v"(PWORD) \
+                     : [w0] "v"(in.w0), [w1] "v"(in.w1), [bp] "v"(in.bp8), [swap] "s"(0x00010203u),        \
+                       [pnd] "v"(p_nd_), [pnb] "v"(p_nb_), [prg] "v"(p_rg_), [psh] "n"(PSHIFT));           \
         const u32 q1_ = l_.x * t_, q2_ = l_.y * t_, q3_ = l_.z * t_, q4_ = l_.w * t_;                      \
         u32 lo_, rg_, nb_, hi_, y1_, y2_, y3_, y4_;                                                        \
         asm volatile("v_sub_co_u32_e64 %[y1], %[c1], %[low], %[q1]\n\t"                                    \
@@ -771,17 +787,17 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_static_quad_k(const u8* __
                      "v_min_u32_dpp %[lo], %[lo], %[lo] " RCX_QP2                                          \
                      "v_add_u32_dpp %[nb], %[nb], %[nb] " RCX_QP2                                          \
                      "v_max_u32_dpp %[hi], %[hi], %[hi] " RCX_QP2                                          \
-                     "v_sub_u32 %[rg], %[lo], %[hi]\n\t"                                                   \
-                     "v_lshl_add_u32 %[nb], %[nd], 4, %[nb]\n\t"     /* the symbol, in all four lanes */    \
-                     "v_lshl_or_b32 %[word], %[nb], %[sh], %[word]"                                        \
+                     "v_sub_u32 %[rg], %[lo], %[hi]"                                                       \
                      : [lo] "=&v"(lo_), [rg] "=&v"(rg_), [nb] "=&v"(nb_), [hi] "=&v"(hi_), [y1] "=&v"(y1_), \
                        [y2] "=&v"(y2_), [y3] "=&v"(y3_), [y4] "=&v"(y4_), [c1] "=&s"(c1_), [c2] "=&s"(c2_),  \
-                       [c3] "=&s"(c3_), [c4] "=&s"(c4_), [word] "+v"(WORD)                                  \
+                       [c3] "=&s"(c3_), [c4] "=&s"(c4_)                                                    \
                      : [low] "v"(in.low), [q1] "v"(q1_), [q2] "v"(q2_), [q3] "v"(q3_), [q4] "v"(q4_),      \
-                       [rem] "v"(rem_), [nd] "v"(node_), [sh] "n"(SHIFT));                                  \
+                       [rem] "v"(rem_));                                                                   \
         in.low = lo_;   /* :504 */                                                                         \
         in.range = rg_; /* :505 */                                                                         \
-        least_range = least_range < rg_ ? least_range : rg_;                                               \
+        p_nd_ = node_;  /* the symbol = node << 4 | nb, in all four lanes */                                \
+        p_nb_ = nb_;                                                                                       \
+        p_rg_ = rg_;                                                                                       \
     }
 
     if (full) {
@@ -799,10 +815,11 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_static_quad_k(const u8* __
                 o4[3] = o_last;
             }
             u32 w0_ = 0, w1_ = 0, w2_ = 0, w3_ = 0;
-            RCX_SQUAD_SYMBOL(w0_, 0) RCX_SQUAD_SYMBOL(w0_, 8) RCX_SQUAD_SYMBOL(w0_, 16) RCX_SQUAD_SYMBOL(w0_, 24)
-            RCX_SQUAD_SYMBOL(w1_, 0) RCX_SQUAD_SYMBOL(w1_, 8) RCX_SQUAD_SYMBOL(w1_, 16) RCX_SQUAD_SYMBOL(w1_, 24)
-            RCX_SQUAD_SYMBOL(w2_, 0) RCX_SQUAD_SYMBOL(w2_, 8) RCX_SQUAD_SYMBOL(w2_, 16) RCX_SQUAD_SYMBOL(w2_, 24)
-            RCX_SQUAD_SYMBOL(w3_, 0) RCX_SQUAD_SYMBOL(w3_, 8) RCX_SQUAD_SYMBOL(w3_, 16) RCX_SQUAD_SYMBOL(w3_, 24)
+            RCX_SQUAD_SYMBOL(0, w0_, 0) RCX_SQUAD_SYMBOL(1, w0_, 0) RCX_SQUAD_SYMBOL(1, w0_, 8) RCX_SQUAD_SYMBOL(1, w0_, 16)
+            RCX_SQUAD_SYMBOL(1, w0_, 24) RCX_SQUAD_SYMBOL(1, w1_, 0) RCX_SQUAD_SYMBOL(1, w1_, 8) RCX_SQUAD_SYMBOL(1, w1_, 16)
+            RCX_SQUAD_SYMBOL(1, w1_, 24) RCX_SQUAD_SYMBOL(1, w2_, 0) RCX_SQUAD_SYMBOL(1, w2_, 8) RCX_SQUAD_SYMBOL(1, w2_, 16)
+            RCX_SQUAD_SYMBOL(1, w2_, 24) RCX_SQUAD_SYMBOL(1, w3_, 0) RCX_SQUAD_SYMBOL(1, w3_, 8) RCX_SQUAD_SYMBOL(1, w3_, 16)
+            RCX_SQUAD_FINISH(w3_, 24)
             U4 o;
             o.x = w0_;
             o.y = w1_;
@@ -824,12 +841,16 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_static_quad_k(const u8* __
             if ((i & 15u) == 0) in.topup();
             if (i < len) { // the 4 lanes of a quad agree
                 u32 sym = 0;
-                RCX_SQUAD_SYMBOL(sym, 0);
+                RCX_SQUAD_SYMBOL(0, sym, 0);
+                RCX_SQUAD_FINISH(sym, 0);
                 if (leader) out[i] = (u8)sym;
             }
         }
     }
 #undef RCX_SQUAD_SYMBOL
+#undef RCX_SQUAD_FINISH
+#undef RCX_SQ_PREV_0
+#undef RCX_SQ_PREV_1
 #undef RCX_QP1
 #undef RCX_QP2
     // the normalisation after the last symbol (it decides whether the input was long enough, cpprcoder.h:506-509)
