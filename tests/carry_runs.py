@@ -11,7 +11,9 @@ import numpy as np
 M = 1 << 32
 
 
-def carry_run_block(n: int, run_len: int, seed: int) -> np.ndarray:
+def carry_run_block(n: int, run_len: int, seed: int, after: int = 0) -> np.ndarray:
+    """`after`: the first symbol index from which the interval may be steered (the run then begins at the next point at which
+    the interval straddles the wrap point by itself: somewhere later in the block, at no particular output position)."""
     rs = np.random.RandomState(seed)
     cnt = [1] * 256
     total = 256
@@ -22,7 +24,7 @@ def carry_run_block(n: int, run_len: int, seed: int) -> np.ndarray:
     while len(out) < n:
         t = rng // total
         c = None
-        if not done and low + total * t > M:  # [low, low + total*t) contains the wrap point
+        if not done and len(out) >= after and low + total * t > M:  # [low, low + total*t) contains the wrap point
             cum = 0
             for s in range(256):
                 lo_s, hi_s = low + cum * t, low + (cum + cnt[s]) * t

@@ -249,6 +249,31 @@ def test_carry_through_long_runs_of_ff(ctx, oracle):
     assert np.array_equal(gpu_decode(ctx, p2, o2, len(plain), 65536)[0], plain)
 
 
+def test_carries_at_many_output_positions(ctx, oracle):
+    """The multi-wave encoder's writer mirrors a window of the newest eight bytes into a 256-byte ring and lets a carry that
+    runs through more than four bytes go on in the ring (csrc/rcx_oct.hpp StagedWriter): runs of 4 .. 40 held 0xFF bytes
+    that begin at many places of a block -- whatever their position relative to the ring's wrap, a word boundary, a chunk
+    of 16 symbols -- must give the reference's stream."""
+    import carry_runs
+    block = 4096
+    parts, runs = [], []
+    for i, run in enumerate([4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 24, 33, 40]):
+        for k, after in enumerate([0, 150, 260, 515, 770, 1290, 2000, 3000]):
+            try:
+                parts.append(carry_runs.carry_run_block(block, run, 9000 + 100 * i + k, after))
+                runs.append(run)
+            except AssertionError:  # (no straddle behind `after` with this seed: the next one)
+                continue
+    assert len(parts) >= 80
+    data = np.concatenate(parts)
+    payload, offsets, _ = gpu_encode(ctx, data, block)
+    slots, sizes = oracle.encode_blocks(data, block, threads=8)
+    assert_same_blocks(payload, offsets, slots, sizes)
+    assert ctx.last_redo(len(runs)) <= sum(r > 24 for r in runs)
+    back, st, _ = gpu_decode(ctx, payload, offsets, len(data), block)
+    assert st == 0 and np.array_equal(back, data)
+
+
 def test_static_carry_through_long_runs_of_ff(ctx, oracle):
     """The same for the static coder's three-wave encoder (rcx_enc_static3_k) and its second pass."""
     import carry_runs
