@@ -627,12 +627,13 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
 // Five waves on four SIMDs: the two lightest (A and the level-1 model wave) are meant to share one.
 //
 // The writer does not store to global memory: scattered 4-byte stores under an EXEC mask were its most
-// expensive step.  Its words go to a per-block ring in LDS (one ds_write_b32 per symbol, to a dummy word
-// when nothing is due), and the level-1 model wave drains the rings once per chunk with 16-byte (the leaf wave,
-// alone on its SIMD, looked like the better place and measured 9 % slower)
-// stores.  The ring keeps the newest RCX_OUT_MARGIN bytes back, so that a carry that runs off the writer's
-// registers (cpprcoder.h:767-781) is resolved in LDS; a run of 0xFF bytes longer than that margin cannot be,
+// expensive step.  Its bytes go to a per-block ring in LDS (StagedWriter: a window of the newest eight bytes mirrored
+// there, two words a symbol), and the level-1 model wave drains the rings once per chunk with 16-byte stores (the leaf
+// wave or the writer itself measured no better: a drain costs its wave the same wherever it runs).
+// The drain keeps the newest RCX_OUT_MARGIN bytes back, so that a carry that runs through more than the newest four
+// bytes (cpprcoder.h:767-781) is resolved in LDS; a run of 0xFF bytes longer than that margin cannot be,
 // and such a block is marked in `redo` and encoded again by rcx_enc_adaptive_k.
+// Level 3 of the model (one group per block) lives in registers of the levels-3+2 wave, the other levels in LDS.
 // ===========================================================================
 #define RCX_MC5_THREADS 320
 #if !defined(RCX_DRAIN_WAVE)
@@ -1091,7 +1092,7 @@ __global__ __launch_bounds__(RCX_MC5_THREADS) void rcx_enc_mc5_k(const u8* __res
     u32* ring2 = reinterpret_cast<u32*>(lds + RCX_MC_LDS_U4);
     u32* final_low = ring2 + RCX_MC5_RING2_DW; // 64 dwords: the arithmetic wave's last low, for the writer's finish()
     u32* out_ring = final_low + RCX_LANES;     // the writer's words on their way to global memory
-    u32* out_dummy = out_ring + RCX_OUT_RING_WORDS * RCX_LANES;
+    u32* out_dummy = out_ring + RCX_OUT_RING_WORDS * RCX_LANES; // (ring slot 64: repeats slot 0 for the writer's pair (63, 64))
     u32* out_pos = out_dummy + RCX_LANES;      // writer -> drain: bytes in the ring so far
     u32* out_drained = out_pos + RCX_LANES;    // drain -> writer's finish: bytes stored so far
 
