@@ -635,9 +635,19 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
 // and such a block is marked in `redo` and encoded again by rcx_enc_adaptive_k.
 // Level 3 of the model (one group per block) lives in registers of the levels-3+2 wave, the other levels in LDS.
 // ===========================================================================
-#define RCX_MC5_THREADS 320
+// Which wave drains the output rings: 5 = a sixth wave that does nothing else (default), 4 = the level-1 model wave (shares
+// its SIMD with the arithmetic wave), 3 = the leaf wave.  The kernel's wave ROLES are numbered 0 arithmetic, 1 writer,
+// 2 model levels 3+2, 3 model leaf level, 4 model level 1, 5 drain; with six waves the hardware's waves 1 and 3 swap roles,
+// so that (a workgroup's wave i runs on SIMD i mod 4) the drain shares a SIMD with the leaf wave, which has the most room.
 #if !defined(RCX_DRAIN_WAVE)
-#define RCX_DRAIN_WAVE 4 /* which model wave drains the output rings: 4 (level 1, shares a SIMD with the arithmetic wave) or 3 (leaf level) */
+#define RCX_DRAIN_WAVE 5
+#endif
+#if RCX_DRAIN_WAVE == 5
+#define RCX_MC5_THREADS 384
+#define RCX_MC5_ROLE(HW) ((HW) == 1u ? 3u : (HW) == 3u ? 1u : (HW))
+#else
+#define RCX_MC5_THREADS 320
+#define RCX_MC5_ROLE(HW) (HW)
 #endif
 // The ring between the model waves and the arithmetic wave: four dwords per symbol and lane.  Kept as 16 contiguous
 // bytes per lane (one ds_read_b128 for the arithmetic wave; the model waves' 4-byte stores hit each bank four times)
@@ -839,7 +849,7 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
 #endif
     U4 piece_ahead;
     piece_ahead.x = piece_ahead.y = piece_ahead.z = piece_ahead.w = 0;
-    if (FULL && wave >= 2 && nchunks > 0) piece_ahead = *reinterpret_cast<const U4*>(in);
+    if (FULL && wave >= 2 && wave <= 4 && nchunks > 0) piece_ahead = *reinterpret_cast<const U4*>(in);
     u32 l3a = 64, l3b = 128, l3c = 192; // wave 2: the level-3 sums (cpprcoder.h:1094-1132: every count 1)
     for (u32 k = 0; k <= nchunks + 1; ++k) {
         if (wave == 0) {
@@ -928,14 +938,14 @@ __device__ __forceinline__ void rcx_mc5_pipeline(u32 wave, u32 lane, u32 len, u3
             const u32 limit = drain_p > RCX_OUT_MARGIN ? (drain_p - RCX_OUT_MARGIN) & ~15u : 0u;
             drained = rcx_drain_piece(wr.ring_lane, payload, drained, limit < cap ? limit : cap, live, drain_piece);
           };
-          if (k >= nchunks && wave == RCX_DRAIN_WAVE) drain_store();
-          if (k < nchunks) {
+          if ((k >= nchunks || RCX_DRAIN_WAVE == 5) && wave == RCX_DRAIN_WAVE) drain_store(); // (a wave that only drains: nothing to wait for)
+          if (k < nchunks && wave <= 4) {
             // ---- model: chunk k ----
             const u32 i0 = k * RCX_MC_CHUNK;
             u32* ws = ring + (k & 1u) * (4 * RCX_MC_CHUNK * RCX_LANES) + RCX_RING_LANE * lane;
             U4 piece;
             if (FULL) piece = piece_ahead;
-            if (wave == RCX_DRAIN_WAVE) {
+            if (RCX_DRAIN_WAVE != 5 && wave == RCX_DRAIN_WAVE) {
                 // The stores go out between the wait for this chunk's input (asked for a chunk ago: it is there) and the
                 // request for the next chunk's: memory operations complete in order as far as s_waitcnt vmcnt can tell, so
                 // a wait for input behind a store just issued would wait for that store (that was 28 cycles a symbol on
@@ -1077,7 +1087,7 @@ __global__ __launch_bounds__(RCX_MC5_THREADS) void rcx_enc_mc5_k(const u8* __res
 {
     __shared__ U4 lds[RCX_MC5_LDS_U4];
     const u32 lane = threadIdx.x & 63u;
-    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u32 wave = RCX_MC5_ROLE(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)); // the wave's ROLE (see RCX_DRAIN_WAVE)
     // lanes_used (1..64) of the 64 lanes carry a block; the others idle along (rcx_api.hip picks it from the
     // block count so that every CU has a workgroup before any workgroup carries 64 blocks)
     const bool in_use = lane < lanes_used;
@@ -1121,7 +1131,7 @@ __global__ __launch_bounds__(RCX_MC5_THREADS) void rcx_enc_mc5_k(const u8* __res
     } else if (wave == 4) {
         v.x = v.y = v.z = v.w = 4;
         for (u32 g = RCX_G_L1; g < RCX_G_L0; ++g) tree.store(g, v);
-    } else {
+    } else if (wave == 3) {
         v.x = v.y = v.z = v.w = 1;
         for (u32 g = RCX_G_L0; g < RCX_GROUPS; ++g) tree.store(g, v);
     }

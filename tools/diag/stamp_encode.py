@@ -11,5 +11,5 @@ for _ in range(2):
 ctx.sync_status()
 out = (C.c_ulonglong * 16)()
 print("rc", rcx.lib().rcx_debug_stamps(out))
-for w in range(5):
+for w in range(6):
     print("wave", w, "total", out[2 * w], "barrier-wait", out[2 * w + 1], "per step total %.1f wait %.1f" % (out[2 * w] / 65536, out[2 * w + 1] / 65536))
