@@ -656,7 +656,7 @@ __global__ __launch_bounds__(64 * WAVES) void rcx_dec_quad_k(const u8* __restric
 #define RCX_RING_PLANAR 0
 #endif
 #if !defined(RCX_MODEL_AHEAD)
-#define RCX_MODEL_AHEAD 1 /* symbols the model waves' LDS reads and updates run ahead of their sums */
+#define RCX_MODEL_AHEAD 2 /* symbols the model waves' LDS reads and updates run ahead of their sums */
 #endif
 #if !defined(RCX_ARITH_AHEAD)
 #define RCX_ARITH_AHEAD 1 /* symbols the arithmetic wave's ring and divisor reads run ahead */
